@@ -1,0 +1,23 @@
+# Builds libmvlpt_hip.so (hand-written gfx950 kernels + C ABI) in-tree, and the CPU oracle helpers.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := mvlpt_amd/csrc
+OBJDIR := build/obj
+SRCS  := $(CSRC)/gemm.hip $(CSRC)/norm.hip $(CSRC)/attention.hip $(CSRC)/glue.hip $(CSRC)/engine.hip
+OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result
+LIB   := mvlpt_amd/libmvlpt_hip.so
+
+all: $(LIB)
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h include/mvlpt_hip.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(FLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -rf build $(LIB)
+
+.PHONY: all clean

@@ -1,0 +1,124 @@
+/* libmvlpt_hip.so — C ABI of the MI355X-native prompted-CLIP hot path.
+ *
+ * Drop-in boundary for the reference's `CustomCLIP.forward` + loss/backward as driven by
+ * `MVLPT.forward_backward` (reference: trainers/mvlpt.py:540-583 and :910-932).  The reference has no FFI
+ * (it is pure Python on PyTorch ops), so each entry point below names the Python call site it replaces;
+ * `INTEGRATION.md` shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain C, raw DEVICE pointers + sizes, no torch types.  The caller (PyTorch-ROCm host code) owns every
+ *     tensor buffer it passes; the library owns only its handle (packed frozen weights, saved activations,
+ *     workspace).
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t): no hidden synchronisation, except that the
+ *     first call at a new, larger problem size grows the workspace (hipMalloc).
+ *   - return 0 on success, <0 on error; `mvlpt_last_error()` gives the message.  One handle per process per
+ *     GPU, not thread-safe (the reference drives the device from a single Python thread).
+ *   - prompt tensors and features cross the boundary as fp32; the towers compute in `compute_dtype`
+ *     (fp16 or bf16 MFMA inputs, fp32 accumulation, fp32 residual stream, fp32 LayerNorm/softmax/CE).
+ *   - token / class / task indexing is integer and exact.
+ */
+#ifndef MVLPT_HIP_H
+#define MVLPT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mvlpt_stream_t; /* hipStream_t */
+
+enum { MVLPT_DT_F32 = 0, MVLPT_DT_F16 = 1, MVLPT_DT_BF16 = 2 };
+enum { MVLPT_LABEL_INT64 = 0, MVLPT_LABEL_PROB_F32 = 1 };
+enum { MVLPT_ERR_ARG = -1, MVLPT_ERR_HIP = -2, MVLPT_ERR_STATE = -3, MVLPT_ERR_UNSUPPORTED = -4 };
+
+/* Architecture of the frozen CLIP (same quantities clip.model.build_model infers, clip/model.py:395-418). */
+typedef struct MvlptArch {
+  int image_resolution, patch_size, vision_width, vision_layers, vision_heads;
+  int context_length, text_width, text_layers, text_heads;
+  int embed_dim;
+  int compute_dtype; /* MVLPT_DT_F16 (reference default PREC, train.py:131) or MVLPT_DT_BF16 */
+} MvlptArch;
+
+int mvlpt_create(const MvlptArch* arch, void** handle);
+int mvlpt_destroy(void* handle);
+const char* mvlpt_last_error(void* handle); /* handle may be NULL for create() failures */
+const char* mvlpt_version(void);
+
+/* Frozen weights (replaces `self.model.to(self.device)` for the CLIP towers, trainers/mvlpt.py:867, with a
+ * one-time pack: 16-bit copy for the forward GEMM and a pre-transposed copy for the dX GEMM — legal because
+ * every non-prompt parameter is frozen, trainers/mvlpt.py:855-858).  `name` is the key of
+ * clip.model.CLIP.state_dict() ("visual.conv1.weight", "transformer.resblocks.3.mlp.c_fc.bias", ...).
+ * `dev_ptr` is a contiguous device tensor of `dtype` (fp32/fp16/bf16).  Unknown names return MVLPT_ERR_ARG. */
+int mvlpt_load_frozen(void* handle, const char* name, const void* dev_ptr, int dtype, const int64_t* shape, int ndim,
+                      mvlpt_stream_t stream);
+/* 0 when every tensor the towers need has been loaded; otherwise <0 and last_error names the first missing. */
+int mvlpt_frozen_ready(void* handle);
+
+/* ImageEncoder.forward (trainers/mvlpt.py:52-93).  image [B,3,R,R] of `image_dtype`; vpt [n_vpt,dv] fp32 or
+ * NULL (shallow prompts, forward_vpt :416-437); vpt_deep [n_deep,n_vpt,dv] fp32 or NULL (deep prompts for
+ * layers 1..n_deep, :73-83).  feat_out [B,embed] fp32.  save_for_bwd != 0 keeps activations for image_bwd. */
+int mvlpt_image_fwd(void* handle, const void* image, int image_dtype, const float* vpt, const float* vpt_deep, int n_vpt,
+                    int n_deep, int B, float* feat_out, int save_for_bwd, mvlpt_stream_t stream);
+/* dX-only backward of the image tower: dfeat [B,embed] fp32 -> dvpt [n_vpt,dv], dvpt_deep [n_deep,n_vpt,dv]
+ * (sum over the batch: prompts are `expand`ed, :75,:424).  Must follow image_fwd(save_for_bwd=1), same B. */
+int mvlpt_image_bwd(void* handle, const float* dfeat, float* dvpt, float* dvpt_deep, mvlpt_stream_t stream);
+
+/* forward_coop + TextEncoder.forward (trainers/mvlpt.py:439-515, 105-130).
+ * prefix [C,1,dt], suffix [C,L-1-n_ctx,dt] fp32 (the `token_prefix` / `token_suffix` buffers, :312-316);
+ * ctx [n_ctx,dt] (ctx_per_class=0) or [C,n_ctx,dt] (CSC, ctx_per_class=1) fp32, NULL when n_ctx == 0;
+ * layout int32 [C,L]: source row per position — 0 = prefix, e>0 = suffix row e-1, e<0 = ctx row -e-1
+ * (encodes the end/middle/front layouts); eot int32 [C] = argmax of tokenized_prompts (:128).
+ * L <= context_length (CUT_CONTEXTLEN gives L < 77, :111-117).  feat_out [C,embed] fp32. */
+int mvlpt_text_fwd(void* handle, const float* prefix, const float* suffix, const float* ctx, int ctx_per_class, int n_ctx,
+                   const int32_t* layout, const int32_t* eot, int C, int L, float* feat_out, int save_for_bwd,
+                   mvlpt_stream_t stream);
+/* dfeat [C,embed] fp32 -> dctx (same shape as ctx).  Must follow text_fwd(save_for_bwd=1). */
+int mvlpt_text_bwd(void* handle, const float* dfeat, float* dctx, mvlpt_stream_t stream);
+
+/* Cosine logits (trainers/mvlpt.py:550-554) with the multiplicative per-task mask (:573-581):
+ * logits[b,c] = exp(logit_scale) * <img_b/|img_b|, txt_c/|txt_c|> * [task_lo[b] <= c < task_hi[b]].
+ * task_lo/task_hi int32 [B] or NULL (no mask).  fp32 throughout. */
+int mvlpt_logits_fwd(void* handle, const float* img_feat, const float* txt_feat, float logit_scale_exp, const int32_t* task_lo,
+                     const int32_t* task_hi, int B, int C, float* logits, mvlpt_stream_t stream);
+/* dlogits [B,C] -> dimg [B,embed], dtxt [C,embed] (either may be NULL).  Uses the features of the last
+ * mvlpt_logits_fwd call on this handle. */
+int mvlpt_logits_bwd(void* handle, const float* dlogits, float* dimg, float* dtxt, mvlpt_stream_t stream);
+
+/* F.cross_entropy(output, label) with mean reduction (trainers/mvlpt.py:931) and its gradient.
+ * labels: int64 [B] (MVLPT_LABEL_INT64) or fp32 probabilities [B,C] (MVLPT_LABEL_PROB_F32, rows already
+ * normalised as in :914-916).  loss [1]; dlogits [B,C] or NULL; ncorrect [1] or NULL (top-1 hits, with
+ * argmax(label) as the target for soft labels, :935-936). */
+int mvlpt_cross_entropy(void* handle, const float* logits, const void* labels, int label_kind, int B, int C, float* loss,
+                        float* dlogits, float* ncorrect, mvlpt_stream_t stream);
+
+/* ---- kernel-level entry points (what the parity tests call; same kernels the towers use) ------------------ */
+/* C[M,N] = A[M,K] * Bt[N,K]^T with epilogue `epi` (0 store16(+bias), 1 bias+QuickGELU (out2 = pre-activation),
+ * 2 fp32 out = acc+bias+resid32, 3 out16 = acc*QuickGELU'(aux16), 4 fp32 store).  K % 64 == 0, N % 4 == 0. */
+int mvlpt_op_gemm(int dtype, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
+                  const float* resid, void* out, void* out2, mvlpt_stream_t stream);
+int mvlpt_op_layernorm_fwd(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
+                           mvlpt_stream_t stream);
+int mvlpt_op_layernorm_bwd(int dtype, const void* dy, const float* x, const float* gamma, const float* resid, float* out32,
+                           void* out16, int rows, int d, mvlpt_stream_t stream);
+/* qkv [N*L,3*H*64] 16-bit -> out [N*L,H*64], lse [N*H*L] (may be NULL) */
+int mvlpt_op_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int N, int L, int H, int causal,
+                           mvlpt_stream_t stream);
+int mvlpt_op_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                           void* dqkv, int N, int L, int H, int causal, mvlpt_stream_t stream);
+int mvlpt_op_cast(int dtype, const float* in, void* out, int64_t n, mvlpt_stream_t stream);
+
+/* ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) --------------------- */
+typedef struct MvlptKernelStat {
+  char name[32];
+  int64_t launches;
+  double ms;    /* sum of event-timed launch durations */
+  double flops; /* algorithmic FLOPs summed over launches (2*M*N*K for GEMM, 4*L*L*64 per head for attention) */
+  double bytes; /* algorithmic HBM bytes summed over launches */
+} MvlptKernelStat;
+int mvlpt_profile_begin(void* handle);
+/* synchronises the recorded events, fills up to `max_stats` entries, returns the number written (or <0) */
+int mvlpt_profile_end(void* handle, MvlptKernelStat* stats, int max_stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVLPT_HIP_H */

@@ -1,0 +1,81 @@
+"""ctypes binding of libmvlpt_hip.so (C ABI in include/mvlpt_hip.h).
+
+There is NO CPU fallback: if the shared library is missing (build it with ``make`` or
+``python -c 'import __graft_entry__ as g; g.build()'``) importing this module raises, and every
+compute call needs a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvlpt_hip.so")
+
+DT_F32, DT_F16, DT_BF16 = 0, 1, 2
+LABEL_INT64, LABEL_PROB_F32 = 0, 1
+EPI_STORE16, EPI_GELU, EPI_RESID32, EPI_GELUBWD, EPI_STORE32 = 0, 1, 2, 3, 4
+
+
+class MvlptArch(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "image_resolution", "patch_size", "vision_width", "vision_layers", "vision_heads",
+        "context_length", "text_width", "text_layers", "text_heads", "embed_dim", "compute_dtype")]
+
+
+class MvlptKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+
+# name -> (restype, argtypes): every symbol include/mvlpt_hip.h declares
+SIGNATURES = {
+    "mvlpt_create": (_i, [C.POINTER(MvlptArch), C.POINTER(_vp)]),
+    "mvlpt_destroy": (_i, [_vp]),
+    "mvlpt_last_error": (C.c_char_p, [_vp]),
+    "mvlpt_version": (C.c_char_p, []),
+    "mvlpt_load_frozen": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i, _vp]),
+    "mvlpt_frozen_ready": (_i, [_vp]),
+    "mvlpt_image_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "mvlpt_image_bwd": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mvlpt_text_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "mvlpt_text_bwd": (_i, [_vp, _vp, _vp, _vp]),
+    "mvlpt_logits_fwd": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _vp]),
+    "mvlpt_logits_bwd": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mvlpt_cross_entropy": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mvlpt_op_gemm": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvlpt_op_layernorm_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mvlpt_op_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mvlpt_op_attention_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvlpt_op_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvlpt_op_cast": (_i, [_i, _vp, _vp, C.c_int64, _vp]),
+    "mvlpt_profile_begin": (_i, [_vp]),
+    "mvlpt_profile_end": (_i, [_vp, C.POINTER(MvlptKernelStat), _i]),
+}
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    if not os.path.isfile(path):
+        raise ImportError(
+            f"{path} not found: build the HIP extension first (`make` at the repo root, or "
+            "`__graft_entry__.build()`); mvlpt_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = load_library()
+
+
+def last_error(handle=None) -> str:
+    msg = lib.mvlpt_last_error(handle)
+    return msg.decode() if msg else ""
+
+
+def check(rc: int, handle=None, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError(f"libmvlpt_hip {what} failed (code {rc}): {last_error(handle) or last_error(None)}")

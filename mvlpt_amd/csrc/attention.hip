@@ -1,0 +1,401 @@
+// Multi-head attention core, head_dim 64, forward and backward (dQ,dK,dV), for the two CLIP towers:
+//   vision  : non-causal, L = 1 + n_vpt + grid^2 (50 / 197..205), nn.MultiheadAttention in
+//             clip/model.py:181-183 called from trainers/mvlpt.py:72,83,85
+//   text    : additive causal mask (clip/model.py:324-330), L <= 77 (CUT_CONTEXTLEN shortens it)
+// scale = 1/sqrt(64); softmax statistics and all accumulation in fp32; P and dS feed the MFMA as 16-bit.
+//
+// gfx950 design: sequences are short, so a whole head's K and V fit in LDS (<= 64 KiB): one workgroup
+// (4 waves) per (sequence, head), each wave owns 16-query tiles.  Scores are computed TRANSPOSED,
+// S^T = K Q^T, so every lane owns ONE query column (q = lane & 15) and four keys per 16-key tile: the
+// softmax row-reduction is in-register plus two wavefront shuffles (xor 16, 32), and the P^T accumulator
+// registers ARE the B operand of the next MFMA (O^T = V^T P^T) with no cross-lane movement: the k-slot
+// (lane>>4)*8 + j of a 32-key block is defined as key 4*(lane>>4) + j of its first 16-key tile for j<4
+// and of its second tile for j>=4; V^T is staged in LDS in exactly that order (two ds_read_b64).
+// K rows are stored 128 B wide with the 16-B chunk index XOR (row & 7) (conflict-free ds_read_b128);
+// V^T rows are padded to (LP + 8) elements = 4*odd dwords (conflict-free ds_read_b64).
+#include "kernels.h"
+
+namespace mvlpt {
+
+constexpr int ATT_MAX_NKT = 16;  // 16 tiles * 16 keys = 256
+int attn_max_len() { return ATT_MAX_NKT * 16; }
+
+// ---- staging helpers -------------------------------------------------------------------------------------
+// row-major [LP][64] 16-bit image, chunk-swizzled; rows >= L zero filled.  src: row stride `ld` elements.
+template <typename T>
+__device__ __forceinline__ void stage_rows(char* dst, const T* src, size_t ld, int L, int LP) {
+  for (int idx = threadIdx.x; idx < LP * 8; idx += 256) {
+    const int row = idx >> 3, c = idx & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < L) v = *(const uint4*)(src + (size_t)row * ld + c * 8);
+    *(uint4*)(dst + row * 128 + ((c ^ (row & 7)) * 16)) = v;
+  }
+}
+// transposed [64][VS] image (VS = LP + 8), zero filled past L
+template <typename T>
+__device__ __forceinline__ void stage_transposed(T* dst, const T* src, size_t ld, int L, int LP, int VS) {
+  // consecutive lanes take consecutive ROWS of one 16-B column chunk: the 2-byte LDS writes of a wave
+  // then fall on consecutive addresses (the row-major mapping would put 8 lanes on one bank, 8-way)
+  for (int idx = threadIdx.x; idx < LP * 8; idx += 256) {
+    const int row = idx % LP, c = idx / LP;
+    typename Vec<T>::v8 v;
+    if (row < L) v = *(const typename Vec<T>::v8*)(src + (size_t)row * ld + c * 8);
+    else for (int e = 0; e < 8; ++e) v[e] = (T)0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[(c * 8 + e) * VS + row] = v[e];
+  }
+}
+// A-operand fragment of a row-major swizzled image: rows tile*16 + (lane&15), k-step ks (32 wide)
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::v8 frag_rows(const char* img, int tile, int ks, int fr, int fg) {
+  return *(const typename Vec<T>::v8*)(img + (tile * 16 + fr) * 128 + (((ks * 4 + fg) ^ (fr & 7)) * 16));
+}
+// A-operand fragment of a transposed image: row (dt*16 + lane&15), k-slots = 32-key block kb
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::v8 frag_transposed(const T* img, int VS, int dt, int kb, int fr, int fg) {
+  const T* p = img + (dt * 16 + fr) * VS + kb * 32 + fg * 4;
+  const typename Vec<T>::v4 lo = *(const typename Vec<T>::v4*)p;
+  const typename Vec<T>::v4 hi = *(const typename Vec<T>::v4*)(p + 16);
+  typename Vec<T>::v8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[e + 4] = hi[e]; }
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::v8 pack8(const f32x4& a, const f32x4& b) {
+  typename Vec<T>::v8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = from_f32<T>(a[e]); r[e + 4] = from_f32<T>(b[e]); }
+  return r;
+}
+__device__ __forceinline__ float quad_sum(float v) {  // reduce over the four lanes sharing lane&15
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+// ======================================================================================= forward
+template <typename T, int NKT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using v8 = typename Vec<T>::v8;
+  using v4 = typename Vec<T>::v4;
+  constexpr int LP = NKT * 16, VS = LP + 8;
+  char* sK = smem;                            // [LP][64] swizzled
+  T* sVt = (T*)(smem + LP * 128);             // [64][VS]
+  const int L = a.L, H = a.H, d = H * 64;
+  const int n = blockIdx.x / H, h = blockIdx.x % H;
+  const size_t ld = (size_t)3 * d;
+  const T* base = (const T*)a.qkv + (size_t)n * L * ld + h * 64;
+  stage_rows<T>(sK, base + d, ld, L, LP);
+  stage_transposed<T>(sVt, base + 2 * d, ld, L, LP, VS);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nqt = (L + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qrow = qt * 16 + fr;
+    const int qr = qrow < L ? qrow : L - 1;
+    const T* qp = base + (size_t)qr * ld + fg * 8;
+    const v8 q0 = *(const v8*)qp, q1 = *(const v8*)(qp + 32);
+    const int nkt = CAUSAL ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;   // key tiles that can be unmasked
+    f32x4 s[NKT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < nkt) {
+        s[kt] = mfma16<T>(frag_rows<T>(sK, kt, 0, fr, fg), q0, s[kt]);
+        s[kt] = mfma16<T>(frag_rows<T>(sK, kt, 1, fr, fg), q1, s[kt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + fg * 4 + r;
+          const bool ok = key < L && (!CAUSAL || key <= qrow);
+          s[kt][r] = ok ? s[kt][r] * 0.125f : -INFINITY;
+          mx = fmaxf(mx, s[kt][r]);
+        }
+      }
+    }
+    mx = quad_max(mx);          // finite: key 0 is always unmasked
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - mx); sum += s[kt][r]; }
+      }
+    }
+    sum = quad_sum(sum);
+    const float inv = 1.0f / sum;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NKT / 2; ++kb) {
+      if (2 * kb < nkt) {
+        const v8 pf = pack8<T>(s[2 * kb], s[2 * kb + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16<T>(frag_transposed<T>(sVt, VS, dt, kb, fr, fg), pf, o[dt]);
+      }
+    }
+    if (qrow < L) {
+      T* op = (T*)a.out + ((size_t)n * L + qrow) * d + h * 64 + fg * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        v4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(o[dt][e] * inv);
+        *(v4*)(op + dt * 16) = w;
+      }
+      if (a.lse && fg == 0) a.lse[((size_t)n * H + h) * L + qrow] = mx + __logf(sum);
+    }
+  }
+}
+
+// ======================================================================================= backward A: dQ (+ delta)
+// per query tile:  S^T, P^T = exp(S^T*scale - lse), dP^T = V dO^T, dS^T = P^T (dP^T - delta) * scale,
+//                  dQ^T = K^T dS^T.   LDS: K rows, V rows, K transposed.
+template <typename T, int NKT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using v8 = typename Vec<T>::v8;
+  using v4 = typename Vec<T>::v4;
+  constexpr int LP = NKT * 16, VS = LP + 8;
+  char* sK = smem;
+  char* sV = smem + LP * 128;
+  T* sKt = (T*)(smem + 2 * LP * 128);
+  const int L = a.L, H = a.H, d = H * 64;
+  const int n = blockIdx.x / H, h = blockIdx.x % H;
+  const size_t ld = (size_t)3 * d;
+  const T* base = (const T*)a.qkv + (size_t)n * L * ld + h * 64;
+  stage_rows<T>(sK, base + d, ld, L, LP);
+  stage_rows<T>(sV, base + 2 * d, ld, L, LP);
+  stage_transposed<T>(sKt, base + d, ld, L, LP, VS);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nqt = (L + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qrow = qt * 16 + fr;
+    const int qr = qrow < L ? qrow : L - 1;
+    const size_t tok = (size_t)n * L + qr;
+    const T* qp = base + (size_t)qr * ld + fg * 8;
+    const v8 q0 = *(const v8*)qp, q1 = *(const v8*)(qp + 32);
+    const T* dop = (const T*)a.dout + tok * d + h * 64 + fg * 8;
+    const T* op = (const T*)a.out + tok * d + h * 64 + fg * 8;
+    const v8 do0 = *(const v8*)dop, do1 = *(const v8*)(dop + 32);
+    const v8 o0 = *(const v8*)op, o1 = *(const v8*)(op + 32);
+    float dl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += to_f32<T>(do0[e]) * to_f32<T>(o0[e]) + to_f32<T>(do1[e]) * to_f32<T>(o1[e]);
+    dl = quad_sum(dl);
+    const float lse = a.lse[((size_t)n * H + h) * L + qr];
+    if (qrow < L && fg == 0) a.delta[((size_t)n * H + h) * L + qrow] = dl;
+    const int nkt = CAUSAL ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;
+    v8 dsf[NKT / 2];     // dS^T packed to 16-bit as soon as a 32-key block is done (register budget)
+#pragma unroll
+    for (int kb = 0; kb < NKT / 2; ++kb) {
+      f32x4 dsv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int kt = 2 * kb + u;
+        dsv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kt < nkt) {
+          f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+          sv = mfma16<T>(frag_rows<T>(sK, kt, 0, fr, fg), q0, sv);
+          sv = mfma16<T>(frag_rows<T>(sK, kt, 1, fr, fg), q1, sv);
+          dp = mfma16<T>(frag_rows<T>(sV, kt, 0, fr, fg), do0, dp);
+          dp = mfma16<T>(frag_rows<T>(sV, kt, 1, fr, fg), do1, dp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + fg * 4 + r;
+            const bool ok = key < L && (!CAUSAL || key <= qrow);
+            const float p = ok ? __expf(sv[r] * 0.125f - lse) : 0.f;
+            dsv[u][r] = p * (dp[r] - dl) * 0.125f;
+          }
+        }
+      }
+      dsf[kb] = pack8<T>(dsv[0], dsv[1]);
+    }
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < NKT / 2; ++kb) {
+      if (2 * kb < nkt) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16<T>(frag_transposed<T>(sKt, VS, dt, kb, fr, fg), dsf[kb], dq[dt]);
+      }
+    }
+    if (qrow < L) {
+      T* gp = (T*)a.dqkv + ((size_t)n * L + qrow) * ld + h * 64 + fg * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        v4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(dq[dt][e]);
+        *(v4*)(gp + dt * 16) = w;
+      }
+    }
+  }
+}
+
+// ======================================================================================= backward B: dK, dV
+// per key tile (col = key = lane&15), looping over 32-query blocks:
+//   S = Q K^T (rows = queries), P, dP = dO V^T, dS ;  dV^T += dO^T P ;  dK^T += Q^T dS.
+// LDS: Q rows, dO rows, Q transposed, dO transposed, lse[LP], delta[LP].
+template <typename T, int NKT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using v8 = typename Vec<T>::v8;
+  using v4 = typename Vec<T>::v4;
+  constexpr int LP = NKT * 16, VS = LP + 8;
+  char* sQ = smem;
+  char* sdO = smem + LP * 128;
+  T* sQt = (T*)(smem + 2 * LP * 128);
+  T* sdOt = sQt + 64 * VS;
+  float* sLse = (float*)(smem + 2 * LP * 128 + 2 * 64 * VS * 2);
+  float* sDel = sLse + LP;
+  const int L = a.L, H = a.H, d = H * 64;
+  const int n = blockIdx.x / H, h = blockIdx.x % H;
+  const size_t ld = (size_t)3 * d;
+  const T* base = (const T*)a.qkv + (size_t)n * L * ld + h * 64;
+  const T* dob = (const T*)a.dout + (size_t)n * L * d + h * 64;
+  stage_rows<T>(sQ, base, ld, L, LP);
+  stage_rows<T>(sdO, dob, (size_t)d, L, LP);
+  stage_transposed<T>(sQt, base, ld, L, LP, VS);
+  stage_transposed<T>(sdOt, dob, (size_t)d, L, LP, VS);
+  for (int i = threadIdx.x; i < LP; i += 256) {
+    sLse[i] = i < L ? a.lse[((size_t)n * H + h) * L + i] : 0.f;
+    sDel[i] = i < L ? a.delta[((size_t)n * H + h) * L + i] : 0.f;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nkt_all = (L + 15) >> 4;
+  for (int kt = wave; kt < nkt_all; kt += 4) {
+    const int key = kt * 16 + fr;
+    const int kr = key < L ? key : L - 1;
+    const T* kp = base + (size_t)kr * ld + d + fg * 8;
+    const v8 k0 = *(const v8*)kp, k1 = *(const v8*)(kp + 32);
+    const v8 v0 = *(const v8*)(kp + d), v1 = *(const v8*)(kp + d + 32);
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int qb0 = CAUSAL ? (kt >> 1) : 0;     // query tiles below the key tile are fully masked
+#pragma unroll
+    for (int qb = 0; qb < NKT / 2; ++qb) {
+      if (qb >= qb0 && qb * 32 < L) {
+        f32x4 p[2], ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int qt = 2 * qb + u;
+          f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+          sv = mfma16<T>(frag_rows<T>(sQ, qt, 0, fr, fg), k0, sv);
+          sv = mfma16<T>(frag_rows<T>(sQ, qt, 1, fr, fg), k1, sv);
+          dp = mfma16<T>(frag_rows<T>(sdO, qt, 0, fr, fg), v0, dp);
+          dp = mfma16<T>(frag_rows<T>(sdO, qt, 1, fr, fg), v1, dp);
+          const f32x4 l4 = *(const f32x4*)(sLse + qt * 16 + fg * 4);
+          const f32x4 d4 = *(const f32x4*)(sDel + qt * 16 + fg * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + fg * 4 + r;
+            const bool ok = q < L && key < L && (!CAUSAL || key <= q);
+            const float pv = ok ? __expf(sv[r] * 0.125f - l4[r]) : 0.f;
+            p[u][r] = pv;
+            ds[u][r] = pv * (dp[r] - d4[r]) * 0.125f;
+          }
+        }
+        const v8 pf = pack8<T>(p[0], p[1]);
+        const v8 dsf = pack8<T>(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[dt] = mfma16<T>(frag_transposed<T>(sdOt, VS, dt, qb, fr, fg), pf, dv[dt]);
+          dk[dt] = mfma16<T>(frag_transposed<T>(sQt, VS, dt, qb, fr, fg), dsf, dk[dt]);
+        }
+      }
+    }
+    if (key < L) {
+      T* gp = (T*)a.dqkv + ((size_t)n * L + key) * ld + d + h * 64 + fg * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        v4 wk, wv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wk[e] = from_f32<T>(dk[dt][e]); wv[e] = from_f32<T>(dv[dt][e]); }
+        *(v4*)(gp + dt * 16) = wk;
+        *(v4*)(gp + d + dt * 16) = wv;
+      }
+    }
+  }
+}
+
+// ======================================================================================= launchers
+template <typename T, int NKT, bool CAUSAL>
+static hipError_t fwd_t(const AttnArgs& a, hipStream_t s) {
+  constexpr int LP = NKT * 16, VS = LP + 8;
+  constexpr int lds = LP * 128 + 64 * VS * 2;
+  static bool set = false;
+  if (!set) { hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NKT, CAUSAL>), dim3(a.N * a.H), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+template <typename T, int NKT, bool CAUSAL>
+static hipError_t bwd_t(const AttnBwdArgs& a, hipStream_t s) {
+  constexpr int LP = NKT * 16, VS = LP + 8;
+  constexpr int lds_a = 2 * LP * 128 + 64 * VS * 2;
+  constexpr int lds_b = 2 * LP * 128 + 2 * 64 * VS * 2 + 2 * LP * 4;
+  static bool set = false;
+  if (!set) {
+    hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, NKT, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
+    hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, NKT, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+    set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, NKT, CAUSAL>), dim3(a.N * a.H), dim3(256), lds_a, s, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, NKT, CAUSAL>), dim3(a.N * a.H), dim3(256), lds_b, s, a);
+  return hipGetLastError();
+}
+
+#define MVLPT_NKT_SWITCH(FN, ARGS)                                  \
+  switch (nkt) {                                                    \
+    case 2: return FN<T, 2, CAUSAL> ARGS;                           \
+    case 4: return FN<T, 4, CAUSAL> ARGS;                           \
+    case 6: return FN<T, 6, CAUSAL> ARGS;                           \
+    case 8: return FN<T, 8, CAUSAL> ARGS;                           \
+    case 10: return FN<T, 10, CAUSAL> ARGS;                         \
+    case 12: return FN<T, 12, CAUSAL> ARGS;                         \
+    case 14: return FN<T, 14, CAUSAL> ARGS;                         \
+    case 16: return FN<T, 16, CAUSAL> ARGS;                         \
+  }                                                                 \
+  return hipErrorInvalidValue;
+
+template <typename T, bool CAUSAL> static hipError_t fwd_n(int nkt, const AttnArgs& a, hipStream_t s) { MVLPT_NKT_SWITCH(fwd_t, (a, s)) }
+template <typename T, bool CAUSAL> static hipError_t bwd_n(int nkt, const AttnBwdArgs& a, hipStream_t s) { MVLPT_NKT_SWITCH(bwd_t, (a, s)) }
+
+static int nkt_for(int L) { int t = (L + 15) / 16; t += t & 1; return t < 2 ? 2 : t; }
+
+hipError_t launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s) {
+  if (a.L <= 0 || a.L > attn_max_len() || a.N <= 0) return hipErrorInvalidValue;
+  const int nkt = nkt_for(a.L);
+  if (dtype == DT_F16) return a.causal ? fwd_n<f16, true>(nkt, a, s) : fwd_n<f16, false>(nkt, a, s);
+  if (dtype == DT_BF16) return a.causal ? fwd_n<bf16, true>(nkt, a, s) : fwd_n<bf16, false>(nkt, a, s);
+  return hipErrorInvalidValue;
+}
+hipError_t launch_attn_bwd(int dtype, const AttnBwdArgs& a, hipStream_t s) {
+  if (a.L <= 0 || a.L > attn_max_len() || a.N <= 0) return hipErrorInvalidValue;
+  const int nkt = nkt_for(a.L);
+  if (dtype == DT_F16) return a.causal ? bwd_n<f16, true>(nkt, a, s) : bwd_n<f16, false>(nkt, a, s);
+  if (dtype == DT_BF16) return a.causal ? bwd_n<bf16, true>(nkt, a, s) : bwd_n<bf16, false>(nkt, a, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace mvlpt

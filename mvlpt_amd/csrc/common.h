@@ -1,0 +1,64 @@
+// Shared device/host helpers for the MI355X (gfx950, wave64) prompt-tuning kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mvlpt {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Vec;
+template <> struct Vec<f16> { using v8 = f16x8; using v4 = f16x4; };
+template <> struct Vec<bf16> { using v8 = bf16x8; using v4 = bf16x4; };
+
+// D(16x16, f32) += A(16x32) * B(32x16), 16-bit inputs.  Operand register layout (wave64):
+//   A: lane l holds A[row = l&15][k = 8*(l>>4) + 0..7]      B: lane l holds B[k = 8*(l>>4) + 0..7][col = l&15]
+//   D: lane l holds D[row = 4*(l>>4) + r][col = l&15], r = 0..3
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(typename Vec<T>::v8 a, typename Vec<T>::v8 b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mfma16<f16>(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mfma16<bf16>(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return static_cast<float>(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return static_cast<T>(v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// QuickGELU (clip/model.py:162-164) and its derivative
+__device__ __forceinline__ float quick_gelu(float u) { return u / (1.0f + __expf(-1.702f * u)); }
+__device__ __forceinline__ float quick_gelu_grad(float u) {
+  float s = 1.0f / (1.0f + __expf(-1.702f * u));
+  return s * (1.0f + 1.702f * u * (1.0f - s));
+}
+
+// async global -> LDS copy, 16 B per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+enum DType { DT_F32 = 0, DT_F16 = 1, DT_BF16 = 2 };
+
+}  // namespace mvlpt

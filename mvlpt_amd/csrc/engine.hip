@@ -1,0 +1,691 @@
+// Host side of libmvlpt_hip.so: the handle (packed frozen CLIP weights, workspaces, saved activations), the
+// layer-by-layer orchestration of the hand-written kernels, and the C ABI declared in include/mvlpt_hip.h.
+//
+// Data layout in HBM (per tower; N sequences of L tokens, width d, token = n*L + i, batch-major):
+//   residual stream x      fp32  [N*L, d]      one buffer per LayerNorm input when activations are saved
+//                                              (2*layers+1 buffers), a single in-place buffer otherwise
+//   h16 (LN output)        16bit [N*L, d]      reused
+//   qkv16                  16bit [N*L, 3d]     per layer when saved (attention backward needs Q,K,V)
+//   attn16 (attention out) 16bit [N*L, d]      per layer when saved (delta = rowsum(dO*O))
+//   lse                    fp32  [N*H*L]       per layer when saved
+//   u16 (pre-GELU)         16bit [N*L, 4d]     per layer when saved;  a16 (GELU out) reused
+//   backward: dx32 fp32 [N*L,d] (in place through the layers), dx16, dh16, dO16 [N*L,d], du16 [N*L,4d],
+//             dqkv16 [N*L,3d], delta [N*H*L]
+// Frozen weights: W16 [out,in] (forward Bt operand) and W16^T [in,out] (dX Bt operand), fp32 biases/LN params.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mvlpt_hip.h"
+#include "kernels.h"
+
+using namespace mvlpt;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ small utils
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+};
+struct Bump {
+  char* base = nullptr; size_t off = 0, cap = 0;
+  template <typename T> T* take(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    T* r = (T*)(base + off); off += bytes; return r;
+  }
+  void* take_bytes(size_t bytes) { return take<char>(bytes); }
+};
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct Linear { void* w = nullptr; void* wt = nullptr; float* b = nullptr; int out = 0, in = 0; };
+struct LNp { float* g = nullptr; float* b = nullptr; };
+struct Block { LNp ln1, ln2; Linear qkv, o, fc, pr; };
+struct TowerW { int width = 0, layers = 0, heads = 0; std::vector<Block> blocks; };
+
+struct TowerState {
+  bool valid = false, saved = false, causal = false;
+  int N = 0, L = 0, d = 0, H = 0, layers = 0;
+  std::vector<float*> x;                 // 2*layers+1 entries (all equal when !saved)
+  std::vector<void*> qkv, attn, u;       // per layer (all equal when !saved)
+  std::vector<float*> lse;
+  void *h16 = nullptr, *a16 = nullptr;
+  float* dx32 = nullptr; void *dx16 = nullptr, *du16 = nullptr, *dh16 = nullptr, *dO16 = nullptr, *dqkv16 = nullptr;
+  float* delta = nullptr; float* scale_dev = nullptr;
+  std::vector<char> skip;                // layer skipped (reference deep-prompt quirk, Appendix A.3)
+};
+
+enum ProfClass { PC_GEMM = 0, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD, PC_GLUE, PC_HEAD, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"gemm_bt", "attention_fwd", "attention_bwd", "layernorm_fwd", "layernorm_bwd",
+                                           "glue", "head_logits_ce"};
+struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
+
+struct Engine {
+  MvlptArch arch{};
+  int dt = DT_F16;
+  std::string err;
+  TowerW vis, txt;
+  // vision extras
+  void* conv_w = nullptr; int Kp = 0; float* cls_emb = nullptr; float* vpos = nullptr; LNp ln_pre, ln_post;
+  void *vproj = nullptr, *vproj_t = nullptr;   // [dv,e] and [e,dv] 16-bit
+  // text extras
+  float* tpos = nullptr; LNp ln_final; void *tproj = nullptr, *tproj_t = nullptr;
+  std::vector<void*> owned;               // every weight allocation (freed in destroy)
+  DevBuf vis_ws, txt_ws, head_ws, ce_ws, tmp;
+  TowerState vs, ts;
+  // vision fwd extras (carved from vis_ws)
+  int vB = 0, v_nvpt = 0, v_ndeep = 0; void* cls16 = nullptr; void* dfeat16_v = nullptr; void* dcls16 = nullptr;
+  // text fwd extras
+  int tC = 0, tL = 0, t_nctx = 0, t_per_class = 0; int32_t* eot_rows = nullptr; int32_t* ctx_pos = nullptr;
+  void* eot16 = nullptr; void* dfeat16_t = nullptr; void* deot16 = nullptr;
+  // head state
+  int hB = 0, hC = 0; float h_scale = 0.f; const int32_t *h_lo = nullptr, *h_hi = nullptr;
+  float *imn = nullptr, *txn = nullptr, *inorm = nullptr, *tnorm = nullptr;
+  // profiling
+  bool prof_on = false; std::vector<ProfRec> prof; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+};
+
+thread_local std::string g_create_err;
+
+int fail(Engine* E, int code, const std::string& msg) { if (E) E->err = msg; else g_create_err = msg; return code; }
+int hipfail(Engine* E, hipError_t e, const char* what) {
+  return fail(E, MVLPT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(E, call) do { hipError_t _e = (call); if (_e != hipSuccess) return hipfail((E), _e, #call); } while (0)
+
+struct ProfScope {
+  Engine* E; hipStream_t s; bool on = false; hipEvent_t b{};
+  ProfScope(Engine* E_, hipStream_t s_, int cls, double flops, double bytes) : E(E_), s(s_) {
+    if (!E || !E->prof_on) return;
+    if (E->ev_used + 2 > E->ev_pool.size()) {
+      if (E->ev_pool.size() >= 65536) return;
+      for (int i = 0; i < 512; ++i) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return; E->ev_pool.push_back(ev); }
+    }
+    hipEvent_t a = E->ev_pool[E->ev_used++]; b = E->ev_pool[E->ev_used++];
+    (void)hipEventRecord(a, s);
+    E->prof.push_back(ProfRec{cls, a, b, flops, bytes});
+    on = true;
+  }
+  ~ProfScope() { if (on) (void)hipEventRecord(b, s); }
+};
+
+// ------------------------------------------------------------------------------------------------ kernel wrappers
+hipError_t gemm(Engine* E, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
+                const float* resid, void* out, void* out2, hipStream_t s, int dtype = -1) {
+  GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
+  const int dt = dtype >= 0 ? dtype : E->dt;
+  const double ob = (epi == EPI_RESID32) ? 8.0 : (epi == EPI_STORE32 ? 4.0 : (epi == EPI_GELUBWD ? 4.0 : 2.0));
+  ProfScope ps(E, s, PC_GEMM, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + ob * M * N + (out2 ? 2.0 * M * N : 0));
+  return launch_gemm(dt, epi, g, s);
+}
+hipError_t ln_fwd(Engine* E, int out_dt, const float* x, const int32_t* idx, int row_mul, const LNp& p, void* y, int rows, int d,
+                  hipStream_t s) {
+  LnFwdArgs a{x, idx, row_mul, p.g, p.b, y, rows, d};
+  ProfScope ps(E, s, PC_LN_FWD, 8.0 * rows * d, (double)rows * d * (4.0 + (out_dt == DT_F32 ? 4.0 : 2.0)));
+  return launch_ln_fwd(out_dt, a, s);
+}
+hipError_t ln_bwd(Engine* E, const void* dy, const float* x, const int32_t* idx, int row_mul, const LNp& p, const float* resid,
+                  float* out32, void* out16, int rows, int d, hipStream_t s, int dtype = -1) {
+  LnBwdArgs a{dy, x, idx, row_mul, p.g, resid, out32, out16, rows, d};
+  ProfScope ps(E, s, PC_LN_BWD, 14.0 * rows * d, (double)rows * d * (2.0 + 4.0 + (resid ? 4.0 : 0.0) + 4.0 + (out16 ? 2.0 : 0.0)));
+  return launch_ln_bwd(dtype >= 0 ? dtype : E->dt, a, s);
+}
+
+// ------------------------------------------------------------------------------------------------ tower workspace
+size_t tower_bytes(const TowerW& W, int N, int L, bool save) {
+  const size_t T = (size_t)N * L, d = W.width, H = W.heads, nl = W.layers;
+  size_t b = 0;
+  b += (save ? (2 * nl + 1) : 1) * align256(T * d * 4);             // x
+  b += align256(T * d * 2);                                          // h16
+  b += (save ? nl : 1) * align256(T * 3 * d * 2);                    // qkv
+  b += (save ? nl : 1) * align256(T * d * 2);                        // attn
+  b += (save ? nl : 1) * align256((size_t)N * H * L * 4);            // lse
+  b += (save ? nl : 1) * align256(T * 4 * d * 2);                    // u
+  b += align256(T * 4 * d * 2);                                      // a16
+  if (save) {
+    b += align256(T * d * 4) + 3 * align256(T * d * 2) + align256(T * d * 2) + align256(T * 4 * d * 2) + align256(T * 3 * d * 2);
+    b += align256((size_t)N * H * L * 4) + 256;
+  }
+  return b + 4096;
+}
+void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool save, bool causal) {
+  const size_t T = (size_t)N * L, d = W.width, H = W.heads; const int nl = W.layers;
+  st = TowerState();
+  st.N = N; st.L = L; st.d = (int)d; st.H = (int)H; st.layers = nl; st.saved = save; st.causal = causal;
+  st.x.resize(2 * nl + 1); st.qkv.resize(nl); st.attn.resize(nl); st.u.resize(nl); st.lse.resize(nl); st.skip.assign(nl, 0);
+  float* x0 = bp.take<float>(T * d);
+  for (int i = 0; i < 2 * nl + 1; ++i) st.x[i] = (save && i > 0) ? bp.take<float>(T * d) : x0;
+  st.h16 = bp.take_bytes(T * d * 2);
+  for (int l = 0; l < nl; ++l) {
+    const bool fresh = save || l == 0;
+    st.qkv[l] = fresh ? bp.take_bytes(T * 3 * d * 2) : st.qkv[0];
+    st.attn[l] = fresh ? bp.take_bytes(T * d * 2) : st.attn[0];
+    st.lse[l] = fresh ? bp.take<float>((size_t)N * H * L) : st.lse[0];
+    st.u[l] = fresh ? bp.take_bytes(T * 4 * d * 2) : st.u[0];
+  }
+  st.a16 = bp.take_bytes(T * 4 * d * 2);
+  if (save) {
+    st.dx32 = bp.take<float>(T * d);
+    st.dx16 = bp.take_bytes(T * d * 2); st.dh16 = bp.take_bytes(T * d * 2); st.dO16 = bp.take_bytes(T * d * 2);
+    st.du16 = bp.take_bytes(T * 4 * d * 2); st.dqkv16 = bp.take_bytes(T * 3 * d * 2);
+    st.delta = bp.take<float>((size_t)N * H * L);
+    st.scale_dev = bp.take<float>(2);
+  }
+  st.valid = true;
+}
+
+// ResidualAttentionBlock.forward (clip/model.py:185-188) on token buffers
+int block_fwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
+  const Block& B = W.blocks[l];
+  const int T = st.N * st.L, d = st.d;
+  float* xin = st.x[2 * l]; float* xmid = st.x[2 * l + 1]; float* xout = st.x[2 * l + 2];
+  HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, B.ln1, st.h16, T, d, s));
+  HIPCHK(E, gemm(E, EPI_STORE16, st.h16, B.qkv.w, T, 3 * d, d, B.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s));
+  {
+    AttnArgs a{st.qkv[l], st.attn[l], st.saved ? st.lse[l] : nullptr, st.N, st.L, st.H, st.causal ? 1 : 0};
+    const double fl = 4.0 * st.L * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0);
+    ProfScope ps(E, s, PC_ATTN_FWD, fl, (double)T * d * 2.0 * 4.0);
+    HIPCHK(E, launch_attn_fwd(E->dt, a, s));
+  }
+  HIPCHK(E, gemm(E, EPI_RESID32, st.attn[l], B.o.w, T, d, d, B.o.b, nullptr, xin, xmid, nullptr, s));
+  HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, B.ln2, st.h16, T, d, s));
+  HIPCHK(E, gemm(E, EPI_GELU, st.h16, B.fc.w, T, 4 * d, d, B.fc.b, nullptr, nullptr, st.a16, st.saved ? st.u[l] : nullptr, s));
+  HIPCHK(E, gemm(E, EPI_RESID32, st.a16, B.pr.w, T, d, 4 * d, B.pr.b, nullptr, xmid, xout, nullptr, s));
+  return 0;
+}
+
+// dX-only backward of one block: dx32/dx16 hold d(block output) on entry and d(block input) on exit
+int block_bwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
+  const Block& B = W.blocks[l];
+  const int T = st.N * st.L, d = st.d;
+  HIPCHK(E, gemm(E, EPI_GELUBWD, st.dx16, B.pr.wt, T, 4 * d, d, nullptr, st.u[l], nullptr, st.du16, nullptr, s));
+  HIPCHK(E, gemm(E, EPI_STORE16, st.du16, B.fc.wt, T, d, 4 * d, nullptr, nullptr, nullptr, st.dh16, nullptr, s));
+  HIPCHK(E, ln_bwd(E, st.dh16, st.x[2 * l + 1], nullptr, 1, B.ln2, st.dx32, st.dx32, st.dx16, T, d, s));
+  HIPCHK(E, gemm(E, EPI_STORE16, st.dx16, B.o.wt, T, d, d, nullptr, nullptr, nullptr, st.dO16, nullptr, s));
+  {
+    AttnBwdArgs a{st.qkv[l], st.attn[l], st.dO16, st.lse[l], st.delta, st.dqkv16, st.N, st.L, st.H, st.causal ? 1 : 0};
+    const double fl = 14.0 * st.L * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0);
+    ProfScope ps(E, s, PC_ATTN_BWD, fl, (double)T * d * 2.0 * 8.0);
+    HIPCHK(E, launch_attn_bwd(E->dt, a, s));
+  }
+  HIPCHK(E, gemm(E, EPI_STORE16, st.dqkv16, B.qkv.wt, T, d, 3 * d, nullptr, nullptr, nullptr, st.dh16, nullptr, s));
+  HIPCHK(E, ln_bwd(E, st.dh16, st.x[2 * l], nullptr, 1, B.ln1, st.dx32, st.dx32, st.dx16, T, d, s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ weight loading
+bool parse_block_name(const char* rest, int* layer, const char** tail) {
+  // rest = "<l>.<tail>"
+  char* endp = nullptr;
+  long l = strtol(rest, &endp, 10);
+  if (endp == rest || *endp != '.') return false;
+  *layer = (int)l; *tail = endp + 1; return true;
+}
+
+int upload_f32(Engine* E, const float* src32, size_t n, float** dst, hipStream_t s) {
+  void* p = nullptr;
+  HIPCHK(E, hipMalloc(&p, n * 4));
+  E->owned.push_back(p);
+  HIPCHK(E, hipMemcpyAsync(p, src32, n * 4, hipMemcpyDeviceToDevice, s));
+  *dst = (float*)p; return 0;
+}
+int pack_linear(Engine* E, const float* w32, int out, int in, Linear* L, hipStream_t s, int ld_in = -1) {
+  const int ld = ld_in > 0 ? ld_in : in;
+  void *w = nullptr, *wt = nullptr;
+  HIPCHK(E, hipMalloc(&w, (size_t)out * ld * 2)); E->owned.push_back(w);
+  HIPCHK(E, hipMalloc(&wt, (size_t)out * in * 2)); E->owned.push_back(wt);
+  HIPCHK(E, launch_pack_weight(E->dt, w32, w, out, in, ld, s));
+  HIPCHK(E, launch_pack_weight_t(E->dt, w32, wt, out, in, s));
+  L->w = w; L->wt = wt; L->out = out; L->in = in; return 0;
+}
+
+int load_block_tensor(Engine* E, TowerW& W, int layer, const char* tail, const float* p, const int64_t* shape, int ndim,
+                      hipStream_t s) {
+  if (layer < 0 || layer >= W.layers) return fail(E, MVLPT_ERR_ARG, "layer index out of range");
+  Block& B = W.blocks[layer];
+  const int d = W.width;
+  auto is2 = [&](int r, int c) { return ndim == 2 && shape[0] == r && shape[1] == c; };
+  auto is1 = [&](int r) { return ndim == 1 && shape[0] == r; };
+  std::string t(tail);
+  if (t == "attn.in_proj_weight") { if (!is2(3 * d, d)) goto bad; return pack_linear(E, p, 3 * d, d, &B.qkv, s); }
+  if (t == "attn.in_proj_bias") { if (!is1(3 * d)) goto bad; return upload_f32(E, p, 3 * d, &B.qkv.b, s); }
+  if (t == "attn.out_proj.weight") { if (!is2(d, d)) goto bad; return pack_linear(E, p, d, d, &B.o, s); }
+  if (t == "attn.out_proj.bias") { if (!is1(d)) goto bad; return upload_f32(E, p, d, &B.o.b, s); }
+  if (t == "mlp.c_fc.weight") { if (!is2(4 * d, d)) goto bad; return pack_linear(E, p, 4 * d, d, &B.fc, s); }
+  if (t == "mlp.c_fc.bias") { if (!is1(4 * d)) goto bad; return upload_f32(E, p, 4 * d, &B.fc.b, s); }
+  if (t == "mlp.c_proj.weight") { if (!is2(d, 4 * d)) goto bad; return pack_linear(E, p, d, 4 * d, &B.pr, s); }
+  if (t == "mlp.c_proj.bias") { if (!is1(d)) goto bad; return upload_f32(E, p, d, &B.pr.b, s); }
+  if (t == "ln_1.weight") { if (!is1(d)) goto bad; return upload_f32(E, p, d, &B.ln1.g, s); }
+  if (t == "ln_1.bias") { if (!is1(d)) goto bad; return upload_f32(E, p, d, &B.ln1.b, s); }
+  if (t == "ln_2.weight") { if (!is1(d)) goto bad; return upload_f32(E, p, d, &B.ln2.g, s); }
+  if (t == "ln_2.bias") { if (!is1(d)) goto bad; return upload_f32(E, p, d, &B.ln2.b, s); }
+  return fail(E, MVLPT_ERR_ARG, std::string("unknown block tensor: ") + tail);
+bad:
+  return fail(E, MVLPT_ERR_ARG, std::string("shape mismatch for block tensor ") + tail);
+}
+
+const char* first_missing(Engine* E) {
+  static thread_local std::string m;
+  auto chk = [&](const void* p, const std::string& n) { if (!p && m.empty()) m = n; };
+  m.clear();
+  chk(E->conv_w, "visual.conv1.weight"); chk(E->cls_emb, "visual.class_embedding"); chk(E->vpos, "visual.positional_embedding");
+  chk(E->ln_pre.g, "visual.ln_pre.weight"); chk(E->ln_pre.b, "visual.ln_pre.bias");
+  chk(E->ln_post.g, "visual.ln_post.weight"); chk(E->ln_post.b, "visual.ln_post.bias"); chk(E->vproj, "visual.proj");
+  chk(E->tpos, "positional_embedding"); chk(E->ln_final.g, "ln_final.weight"); chk(E->ln_final.b, "ln_final.bias");
+  chk(E->tproj, "text_projection");
+  for (int t = 0; t < 2; ++t) {
+    TowerW& W = t ? E->txt : E->vis;
+    const std::string pre = t ? "transformer.resblocks." : "visual.transformer.resblocks.";
+    for (int l = 0; l < W.layers; ++l) {
+      const Block& B = W.blocks[l]; const std::string q = pre + std::to_string(l) + ".";
+      chk(B.qkv.w, q + "attn.in_proj_weight"); chk(B.qkv.b, q + "attn.in_proj_bias");
+      chk(B.o.w, q + "attn.out_proj.weight"); chk(B.o.b, q + "attn.out_proj.bias");
+      chk(B.fc.w, q + "mlp.c_fc.weight"); chk(B.fc.b, q + "mlp.c_fc.bias");
+      chk(B.pr.w, q + "mlp.c_proj.weight"); chk(B.pr.b, q + "mlp.c_proj.bias");
+      chk(B.ln1.g, q + "ln_1.weight"); chk(B.ln1.b, q + "ln_1.bias"); chk(B.ln2.g, q + "ln_2.weight"); chk(B.ln2.b, q + "ln_2.bias");
+    }
+  }
+  return m.empty() ? nullptr : m.c_str();
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char* mvlpt_version(void) { return "mvlpt_hip 0.1 (gfx950)"; }
+
+const char* mvlpt_last_error(void* h) { return h ? ((Engine*)h)->err.c_str() : g_create_err.c_str(); }
+
+int mvlpt_create(const MvlptArch* a, void** handle) {
+  if (!a || !handle) return fail(nullptr, MVLPT_ERR_ARG, "null argument");
+  if (a->compute_dtype != MVLPT_DT_F16 && a->compute_dtype != MVLPT_DT_BF16)
+    return fail(nullptr, MVLPT_ERR_ARG, "compute_dtype must be MVLPT_DT_F16 or MVLPT_DT_BF16");
+  if (a->vision_width != a->vision_heads * 64 || a->text_width != a->text_heads * 64)
+    return fail(nullptr, MVLPT_ERR_UNSUPPORTED, "head_dim must be 64 (CLIP ViT: heads = width // 64)");
+  if (a->vision_width % 128 || a->text_width % 128 || a->embed_dim % 64)
+    return fail(nullptr, MVLPT_ERR_UNSUPPORTED, "widths must be multiples of 128 and embed_dim of 64");
+  if (a->patch_size <= 0 || a->image_resolution % a->patch_size)
+    return fail(nullptr, MVLPT_ERR_ARG, "image_resolution must be a multiple of patch_size");
+  if (a->vision_layers <= 0 || a->text_layers <= 0 || a->context_length <= 0)
+    return fail(nullptr, MVLPT_ERR_ARG, "bad layer count / context length");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, MVLPT_ERR_HIP, "no HIP device visible: libmvlpt_hip needs an AMD GPU (there is no CPU fallback)");
+  Engine* E = new Engine();
+  E->arch = *a; E->dt = a->compute_dtype;
+  E->vis.width = a->vision_width; E->vis.layers = a->vision_layers; E->vis.heads = a->vision_heads;
+  E->vis.blocks.resize(a->vision_layers);
+  E->txt.width = a->text_width; E->txt.layers = a->text_layers; E->txt.heads = a->text_heads;
+  E->txt.blocks.resize(a->text_layers);
+  const int K = 3 * a->patch_size * a->patch_size;
+  E->Kp = (K + 63) / 64 * 64;
+  *handle = E;
+  return 0;
+}
+
+int mvlpt_destroy(void* h) {
+  if (!h) return 0;
+  Engine* E = (Engine*)h;
+  (void)hipDeviceSynchronize();
+  for (void* p : E->owned) (void)hipFree(p);
+  for (hipEvent_t ev : E->ev_pool) (void)hipEventDestroy(ev);
+  delete E;
+  return 0;
+}
+
+int mvlpt_load_frozen(void* h, const char* name, const void* dev_ptr, int dtype, const int64_t* shape, int ndim,
+                      mvlpt_stream_t stream) {
+  Engine* E = (Engine*)h;
+  if (!E || !name || !dev_ptr || !shape || ndim < 0 || ndim > 4) return fail(E, MVLPT_ERR_ARG, "null/invalid argument");
+  hipStream_t s = (hipStream_t)stream;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+  std::string nm(name);
+  if (nm == "logit_scale" || nm == "token_embedding.weight") return 0;  // not used by the towers
+  // stage as fp32
+  const float* p32 = (const float*)dev_ptr;
+  if (dtype != MVLPT_DT_F32) {
+    HIPCHK(E, E->tmp.reserve(n * 4));
+    HIPCHK(E, launch_cast_any_to_f32(dtype, dev_ptr, (float*)E->tmp.p, n, s));
+    p32 = (const float*)E->tmp.p;
+  }
+  const MvlptArch& A = E->arch;
+  const int dv = A.vision_width, dtw = A.text_width, e = A.embed_dim;
+  const int G2 = (A.image_resolution / A.patch_size) * (A.image_resolution / A.patch_size);
+  auto is1 = [&](int r) { return ndim == 1 && shape[0] == r; };
+  auto is2 = [&](int r, int c) { return ndim == 2 && shape[0] == r && shape[1] == c; };
+  int rc = 0;
+  const char* vb = "visual.transformer.resblocks.";
+  const char* tb = "transformer.resblocks.";
+  if (nm.rfind(vb, 0) == 0 || nm.rfind(tb, 0) == 0) {
+    const bool isv = nm.rfind(vb, 0) == 0;
+    int layer; const char* tail;
+    if (!parse_block_name(name + strlen(isv ? vb : tb), &layer, &tail)) return fail(E, MVLPT_ERR_ARG, "malformed block name: " + nm);
+    rc = load_block_tensor(E, isv ? E->vis : E->txt, layer, tail, p32, shape, ndim, s);
+  } else if (nm == "visual.conv1.weight") {
+    if (!(ndim == 4 && shape[0] == dv && shape[1] == 3 && shape[2] == A.patch_size && shape[3] == A.patch_size))
+      return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm);
+    void* w = nullptr;
+    HIPCHK(E, hipMalloc(&w, (size_t)dv * E->Kp * 2)); E->owned.push_back(w);
+    HIPCHK(E, launch_pack_weight(E->dt, p32, w, dv, 3 * A.patch_size * A.patch_size, E->Kp, s));
+    E->conv_w = w;
+  } else if (nm == "visual.class_embedding") { if (!is1(dv)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->cls_emb, s);
+  } else if (nm == "visual.positional_embedding") { if (!is2(G2 + 1, dv)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->vpos, s);
+  } else if (nm == "visual.ln_pre.weight") { if (!is1(dv)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->ln_pre.g, s);
+  } else if (nm == "visual.ln_pre.bias") { if (!is1(dv)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->ln_pre.b, s);
+  } else if (nm == "visual.ln_post.weight") { if (!is1(dv)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->ln_post.g, s);
+  } else if (nm == "visual.ln_post.bias") { if (!is1(dv)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->ln_post.b, s);
+  } else if (nm == "visual.proj") {
+    if (!is2(dv, e)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm);
+    Linear L;  // proj is [in=dv, out=e]: forward Bt = proj^T [e,dv]; dX Bt = proj [dv,e]
+    rc = pack_linear(E, p32, dv, e, &L, s);
+    E->vproj = L.w; E->vproj_t = L.wt;
+  } else if (nm == "positional_embedding") { if (!is2(A.context_length, dtw)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->tpos, s);
+  } else if (nm == "ln_final.weight") { if (!is1(dtw)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->ln_final.g, s);
+  } else if (nm == "ln_final.bias") { if (!is1(dtw)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->ln_final.b, s);
+  } else if (nm == "text_projection") {
+    if (!is2(dtw, e)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm);
+    Linear L;
+    rc = pack_linear(E, p32, dtw, e, &L, s);
+    E->tproj = L.w; E->tproj_t = L.wt;
+  } else {
+    return fail(E, MVLPT_ERR_ARG, "unknown frozen tensor name: " + nm);
+  }
+  if (rc) return rc;
+  if (dtype != MVLPT_DT_F32) HIPCHK(E, hipStreamSynchronize(s));  // tmp is reused by the next call
+  return 0;
+}
+
+int mvlpt_frozen_ready(void* h) {
+  Engine* E = (Engine*)h;
+  if (!E) return MVLPT_ERR_ARG;
+  const char* m = first_missing(E);
+  if (m) return fail(E, MVLPT_ERR_STATE, std::string("frozen tensor not loaded: ") + m);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ image tower
+int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vpt, const float* vpt_deep, int n_vpt, int n_deep,
+                    int B, float* feat_out, int save_for_bwd, mvlpt_stream_t stream) {
+  Engine* E = (Engine*)h;
+  if (!E || !image || !feat_out || B <= 0) return fail(E, MVLPT_ERR_ARG, "image_fwd: null/invalid argument");
+  if (int rc = mvlpt_frozen_ready(h)) return rc;
+  if ((n_vpt > 0) != (vpt != nullptr)) return fail(E, MVLPT_ERR_ARG, "image_fwd: vpt pointer and n_vpt disagree");
+  if ((n_deep > 0) != (vpt_deep != nullptr) || (n_deep > 0 && n_vpt <= 0)) return fail(E, MVLPT_ERR_ARG, "image_fwd: deep prompts need vpt");
+  hipStream_t s = (hipStream_t)stream;
+  const MvlptArch& A = E->arch;
+  const int G = A.image_resolution / A.patch_size, G2 = G * G, dv = A.vision_width, e = A.embed_dim;
+  const int Lv = 1 + n_vpt + G2;
+  if (Lv > attn_max_len()) return fail(E, MVLPT_ERR_UNSUPPORTED, "image_fwd: sequence length > 256 not supported yet");
+  const bool save = save_for_bwd != 0;
+  const size_t npatch = (size_t)B * G2;
+  size_t need = tower_bytes(E->vis, B, Lv, save) + align256(npatch * E->Kp * 2) + align256(npatch * dv * 4) +
+                3 * align256((size_t)B * dv * 2) + align256((size_t)B * e * 2) + 4096;
+  E->vs.valid = false;
+  HIPCHK(E, E->vis_ws.reserve(need));
+  Bump bp; bp.base = (char*)E->vis_ws.p; bp.cap = E->vis_ws.cap;
+  void* patches = bp.take_bytes(npatch * E->Kp * 2);
+  float* pe = bp.take<float>(npatch * dv);
+  E->cls16 = bp.take_bytes((size_t)B * dv * 2);
+  E->dcls16 = bp.take_bytes((size_t)B * dv * 2);
+  E->dfeat16_v = bp.take_bytes((size_t)B * e * 2);
+  carve_tower(bp, E->vis, E->vs, B, Lv, save, false);
+  TowerState& st = E->vs;
+  E->vB = B; E->v_nvpt = n_vpt; E->v_ndeep = n_deep;
+
+  { ProfScope ps(E, s, PC_GLUE, 0, (double)npatch * E->Kp * 6.0);
+    HIPCHK(E, launch_patchify(E->dt, image, image_dtype, patches, B, A.image_resolution, A.patch_size, E->Kp, s)); }
+  HIPCHK(E, gemm(E, EPI_STORE32, patches, E->conv_w, (int)npatch, dv, E->Kp, nullptr, nullptr, nullptr, pe, nullptr, s));
+  { ProfScope ps(E, s, PC_GLUE, 0, (double)B * Lv * dv * 8.0);
+    HIPCHK(E, launch_assemble_tokens(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, vpt, n_vpt, st.x[0], B, G2, dv, s)); }
+  for (int l = 0; l < E->vis.layers; ++l) {
+    if (l > 0 && n_deep > 0) {
+      if (l <= n_deep) {
+        ProfScope ps(E, s, PC_GLUE, 0, (double)B * n_vpt * dv * 4.0);
+        HIPCHK(E, launch_overwrite_rows(vpt_deep + (size_t)(l - 1) * n_vpt * dv, n_vpt, st.x[2 * l], B, Lv, dv, s));
+      } else {
+        // reference quirk (trainers/mvlpt.py:71-83 has no `else`): the layer is skipped entirely
+        st.skip[l] = 1;
+        if (st.saved) {
+          HIPCHK(E, hipMemcpyAsync(st.x[2 * l + 2], st.x[2 * l], (size_t)B * Lv * dv * 4, hipMemcpyDeviceToDevice, s));
+        }
+        continue;
+      }
+    }
+    if (int rc = block_fwd(E, E->vis, st, l, s)) return rc;
+  }
+  // ln_post on the CLS row, then @ proj   (trainers/mvlpt.py:88-91)
+  HIPCHK(E, ln_fwd(E, E->dt, st.x[2 * E->vis.layers], nullptr, Lv, E->ln_post, E->cls16, B, dv, s));
+  HIPCHK(E, gemm(E, EPI_STORE32, E->cls16, E->vproj_t, B, e, dv, nullptr, nullptr, nullptr, feat_out, nullptr, s));
+  return 0;
+}
+
+int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, mvlpt_stream_t stream) {
+  Engine* E = (Engine*)h;
+  if (!E || !dfeat) return fail(E, MVLPT_ERR_ARG, "image_bwd: null argument");
+  TowerState& st = E->vs;
+  if (!st.valid || !st.saved) return fail(E, MVLPT_ERR_STATE, "image_bwd: call image_fwd(save_for_bwd=1) first");
+  if ((E->v_nvpt > 0 && !dvpt) || (E->v_ndeep > 0 && !dvpt_deep)) return fail(E, MVLPT_ERR_ARG, "image_bwd: missing gradient output");
+  hipStream_t s = (hipStream_t)stream;
+  const MvlptArch& A = E->arch;
+  const int B = E->vB, dv = A.vision_width, e = A.embed_dim, Lv = st.L, n = E->v_nvpt;
+  const size_t T = (size_t)B * Lv;
+  { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 10.0);
+    HIPCHK(E, launch_grad_scale(dfeat, (size_t)B * e, 64.0f, st.scale_dev, s));
+    HIPCHK(E, launch_cast_f32_to16(E->dt, dfeat, E->dfeat16_v, (size_t)B * e, st.scale_dev, s)); }
+  HIPCHK(E, gemm(E, EPI_STORE16, E->dfeat16_v, E->vproj, B, dv, e, nullptr, nullptr, nullptr, E->dcls16, nullptr, s));
+  { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 4.0);
+    HIPCHK(E, launch_zero(st.dx32, T * dv * 4, s)); }
+  HIPCHK(E, ln_bwd(E, E->dcls16, st.x[2 * st.layers], nullptr, Lv, E->ln_post, nullptr, st.dx32, nullptr, B, dv, s));
+  { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 6.0);
+    HIPCHK(E, launch_cast_f32_to16(E->dt, st.dx32, st.dx16, T * dv, nullptr, s)); }
+  for (int l = st.layers - 1; l >= 0; --l) {
+    if (st.skip[l]) continue;
+    if (int rc = block_bwd(E, E->vis, st, l, s)) return rc;
+    if (l > 0 && E->v_ndeep > 0 && l <= E->v_ndeep) {
+      ProfScope ps(E, s, PC_GLUE, 0, (double)B * n * dv * 10.0);
+      HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt_deep + (size_t)(l - 1) * n * dv,
+                                          st.scale_dev, 1, s));
+    }
+  }
+  if (n > 0) {
+    ProfScope ps(E, s, PC_GLUE, 0, (double)B * n * dv * 4.0);
+    HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt, st.scale_dev, 0, s));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ text tower
+int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const float* ctx, int ctx_per_class, int n_ctx,
+                   const int32_t* layout, const int32_t* eot, int C, int L, float* feat_out, int save_for_bwd,
+                   mvlpt_stream_t stream) {
+  Engine* E = (Engine*)h;
+  if (!E || !prefix || !suffix || !layout || !eot || !feat_out || C <= 0 || L <= 0)
+    return fail(E, MVLPT_ERR_ARG, "text_fwd: null/invalid argument");
+  if (int rc = mvlpt_frozen_ready(h)) return rc;
+  if ((n_ctx > 0) != (ctx != nullptr) || n_ctx < 0 || n_ctx > L - 2) return fail(E, MVLPT_ERR_ARG, "text_fwd: ctx pointer and n_ctx disagree");
+  const MvlptArch& A = E->arch;
+  if (L > A.context_length) return fail(E, MVLPT_ERR_ARG, "text_fwd: L exceeds context_length");
+  if (L > attn_max_len()) return fail(E, MVLPT_ERR_UNSUPPORTED, "text_fwd: L > 256");
+  hipStream_t s = (hipStream_t)stream;
+  const int dtw = A.text_width, e = A.embed_dim;
+  const bool save = save_for_bwd != 0;
+  size_t need = tower_bytes(E->txt, C, L, save) + 3 * align256((size_t)C * dtw * 2) + align256((size_t)C * e * 2) +
+                align256((size_t)C * 4) + align256((size_t)C * (n_ctx > 0 ? n_ctx : 1) * 4) + 4096;
+  E->ts.valid = false;
+  HIPCHK(E, E->txt_ws.reserve(need));
+  Bump bp; bp.base = (char*)E->txt_ws.p; bp.cap = E->txt_ws.cap;
+  E->eot16 = bp.take_bytes((size_t)C * dtw * 2);
+  E->deot16 = bp.take_bytes((size_t)C * dtw * 2);
+  E->dfeat16_t = bp.take_bytes((size_t)C * e * 2);
+  E->eot_rows = bp.take<int32_t>(C);
+  E->ctx_pos = bp.take<int32_t>((size_t)C * (n_ctx > 0 ? n_ctx : 1));
+  carve_tower(bp, E->txt, E->ts, C, L, save, true);
+  TowerState& st = E->ts;
+  E->tC = C; E->tL = L; E->t_nctx = n_ctx; E->t_per_class = ctx_per_class;
+  { ProfScope ps(E, s, PC_GLUE, 0, (double)C * L * dtw * 12.0);
+    HIPCHK(E, launch_assemble_prompts(prefix, suffix, ctx, ctx_per_class, n_ctx, layout, E->tpos, st.x[0], C, L, dtw, s));
+    HIPCHK(E, launch_eot_rows(eot, E->eot_rows, C, L, s));
+    if (save && n_ctx > 0) HIPCHK(E, launch_build_ctx_pos(layout, E->ctx_pos, C, L, n_ctx, s)); }
+  for (int l = 0; l < E->txt.layers; ++l)
+    if (int rc = block_fwd(E, E->txt, st, l, s)) return rc;
+  HIPCHK(E, ln_fwd(E, E->dt, st.x[2 * E->txt.layers], E->eot_rows, 1, E->ln_final, E->eot16, C, dtw, s));
+  HIPCHK(E, gemm(E, EPI_STORE32, E->eot16, E->tproj_t, C, e, dtw, nullptr, nullptr, nullptr, feat_out, nullptr, s));
+  return 0;
+}
+
+int mvlpt_text_bwd(void* h, const float* dfeat, float* dctx, mvlpt_stream_t stream) {
+  Engine* E = (Engine*)h;
+  if (!E || !dfeat || !dctx) return fail(E, MVLPT_ERR_ARG, "text_bwd: null argument");
+  TowerState& st = E->ts;
+  if (!st.valid || !st.saved) return fail(E, MVLPT_ERR_STATE, "text_bwd: call text_fwd(save_for_bwd=1) first");
+  if (E->t_nctx <= 0) return fail(E, MVLPT_ERR_STATE, "text_bwd: the forward had no context tokens");
+  hipStream_t s = (hipStream_t)stream;
+  const MvlptArch& A = E->arch;
+  const int C = E->tC, L = E->tL, dtw = A.text_width, e = A.embed_dim;
+  const size_t T = (size_t)C * L;
+  { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dtw * 10.0);
+    HIPCHK(E, launch_grad_scale(dfeat, (size_t)C * e, 64.0f, st.scale_dev, s));
+    HIPCHK(E, launch_cast_f32_to16(E->dt, dfeat, E->dfeat16_t, (size_t)C * e, st.scale_dev, s)); }
+  HIPCHK(E, gemm(E, EPI_STORE16, E->dfeat16_t, E->tproj, C, dtw, e, nullptr, nullptr, nullptr, E->deot16, nullptr, s));
+  { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dtw * 4.0);
+    HIPCHK(E, launch_zero(st.dx32, T * dtw * 4, s)); }
+  HIPCHK(E, ln_bwd(E, E->deot16, st.x[2 * st.layers], E->eot_rows, 1, E->ln_final, nullptr, st.dx32, nullptr, C, dtw, s));
+  { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dtw * 6.0);
+    HIPCHK(E, launch_cast_f32_to16(E->dt, st.dx32, st.dx16, T * dtw, nullptr, s)); }
+  for (int l = st.layers - 1; l >= 0; --l)
+    if (int rc = block_bwd(E, E->txt, st, l, s)) return rc;
+  { ProfScope ps(E, s, PC_GLUE, 0, (double)C * E->t_nctx * dtw * 4.0);
+    HIPCHK(E, launch_gather_ctx_grad(st.dx32, E->ctx_pos, C, L, dtw, E->t_nctx, E->t_per_class, dctx, st.scale_dev, s)); }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ head
+static int head_reserve(Engine* E, int B, int C) {
+  const int e = E->arch.embed_dim;
+  const size_t need = align256((size_t)B * e * 4) + align256((size_t)C * e * 4) + align256((size_t)B * 4) +
+                      align256((size_t)C * 4) + 4096;
+  HIPCHK(E, E->head_ws.reserve(need));
+  Bump bp; bp.base = (char*)E->head_ws.p;
+  E->imn = bp.take<float>((size_t)B * e); E->txn = bp.take<float>((size_t)C * e);
+  E->inorm = bp.take<float>(B); E->tnorm = bp.take<float>(C);
+  return 0;
+}
+
+int mvlpt_logits_fwd(void* h, const float* img, const float* txt, float scale, const int32_t* lo, const int32_t* hi, int B, int C,
+                     float* logits, mvlpt_stream_t stream) {
+  Engine* E = (Engine*)h;
+  if (!E || !img || !txt || !logits || B <= 0 || C <= 0 || ((lo == nullptr) != (hi == nullptr)))
+    return fail(E, MVLPT_ERR_ARG, "logits_fwd: null/invalid argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int e = E->arch.embed_dim;
+  E->hB = 0;
+  if (int rc = head_reserve(E, B, C)) return rc;
+  ProfScope ps(E, s, PC_HEAD, 2.0 * B * C * e, 4.0 * ((double)B * e + (double)C * e + (double)B * C));
+  HIPCHK(E, launch_normalize_rows(img, E->imn, E->inorm, B, e, s));
+  HIPCHK(E, launch_normalize_rows(txt, E->txn, E->tnorm, C, e, s));
+  HIPCHK(E, launch_logits(E->imn, E->txn, scale, lo, hi, logits, B, C, e, s));
+  E->hB = B; E->hC = C; E->h_scale = scale; E->h_lo = lo; E->h_hi = hi;
+  return 0;
+}
+
+int mvlpt_logits_bwd(void* h, const float* dlogits, float* dimg, float* dtxt, mvlpt_stream_t stream) {
+  Engine* E = (Engine*)h;
+  if (!E || !dlogits) return fail(E, MVLPT_ERR_ARG, "logits_bwd: null argument");
+  if (E->hB <= 0 || !E->imn) return fail(E, MVLPT_ERR_STATE, "logits_bwd: call logits_fwd first");
+  hipStream_t s = (hipStream_t)stream;
+  const int e = E->arch.embed_dim;
+  ProfScope ps(E, s, PC_HEAD, 4.0 * E->hB * E->hC * e, 4.0 * ((double)E->hB * e + (double)E->hC * e + (double)E->hB * E->hC) * 2);
+  HIPCHK(E, launch_logits_bwd(dlogits, E->imn, E->txn, E->inorm, E->tnorm, E->h_scale, E->h_lo, E->h_hi, dimg, dtxt, E->hB, E->hC, e, s));
+  return 0;
+}
+
+int mvlpt_cross_entropy(void* h, const float* logits, const void* labels, int kind, int B, int C, float* loss, float* dlogits,
+                        float* ncorrect, mvlpt_stream_t stream) {
+  Engine* E = (Engine*)h;
+  if (!E || !logits || !labels || !loss || B <= 0 || C <= 0 || (kind != 0 && kind != 1))
+    return fail(E, MVLPT_ERR_ARG, "cross_entropy: null/invalid argument");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(E, E->ce_ws.reserve((size_t)2 * B * 4 + 256));
+  ProfScope ps(E, s, PC_HEAD, 8.0 * B * C, 4.0 * 3.0 * B * C);
+  HIPCHK(E, launch_cross_entropy(logits, labels, kind, B, C, (float*)E->ce_ws.p, loss, dlogits, ncorrect, s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ kernel-level ops
+#define OPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(_e); return MVLPT_ERR_HIP; } } while (0)
+
+int mvlpt_op_gemm(int dtype, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
+                  const float* resid, void* out, void* out2, mvlpt_stream_t stream) {
+  GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
+  OPCHK(launch_gemm(dtype, epi, g, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_layernorm_fwd(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
+                           mvlpt_stream_t stream) {
+  LnFwdArgs a{x, nullptr, 1, gamma, beta, y, rows, d};
+  OPCHK(launch_ln_fwd(out_dtype, a, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_layernorm_bwd(int dtype, const void* dy, const float* x, const float* gamma, const float* resid, float* out32,
+                           void* out16, int rows, int d, mvlpt_stream_t stream) {
+  LnBwdArgs a{dy, x, nullptr, 1, gamma, resid, out32, out16, rows, d};
+  OPCHK(launch_ln_bwd(dtype, a, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int N, int L, int H, int causal,
+                           mvlpt_stream_t stream) {
+  AttnArgs a{qkv, out, lse, N, L, H, causal};
+  OPCHK(launch_attn_fwd(dtype, a, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                           void* dqkv, int N, int L, int H, int causal, mvlpt_stream_t stream) {
+  AttnBwdArgs a{qkv, out, dout, lse, delta, dqkv, N, L, H, causal};
+  OPCHK(launch_attn_bwd(dtype, a, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_cast(int dtype, const float* in, void* out, int64_t n, mvlpt_stream_t stream) {
+  OPCHK(launch_cast_f32_to16(dtype, in, out, (size_t)n, nullptr, (hipStream_t)stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+int mvlpt_profile_begin(void* h) {
+  Engine* E = (Engine*)h;
+  if (!E) return MVLPT_ERR_ARG;
+  E->prof.clear(); E->ev_used = 0; E->prof_on = true;
+  return 0;
+}
+int mvlpt_profile_end(void* h, MvlptKernelStat* stats, int max_stats) {
+  Engine* E = (Engine*)h;
+  if (!E || !stats || max_stats <= 0) return MVLPT_ERR_ARG;
+  E->prof_on = false;
+  MvlptKernelStat acc[PC_COUNT];
+  for (int i = 0; i < PC_COUNT; ++i) { memset(&acc[i], 0, sizeof(acc[i])); snprintf(acc[i].name, sizeof(acc[i].name), "%s", kProfNames[i]); }
+  for (const ProfRec& r : E->prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    acc[r.cls].launches += 1; acc[r.cls].ms += ms; acc[r.cls].flops += r.flops; acc[r.cls].bytes += r.bytes;
+  }
+  int n = 0;
+  for (int i = 0; i < PC_COUNT && n < max_stats; ++i) if (acc[i].launches) stats[n++] = acc[i];
+  E->prof.clear(); E->ev_used = 0;
+  return n;
+}
+
+}  // extern "C"

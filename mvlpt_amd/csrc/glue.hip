@@ -1,0 +1,512 @@
+// HBM-bound glue kernels around the GEMM / LayerNorm / attention kernels: patch extraction, token and prompt
+// assembly with the learnable prompt rows spliced in, prompt-gradient reductions, casts / weight packing, and
+// the fp32 head (cosine logits + cross-entropy).  All coalesced along the feature dimension, 16-byte
+// accesses where the layout allows; reductions use wavefront shuffles.
+#include "kernels.h"
+
+namespace mvlpt {
+
+template <typename T> __device__ __forceinline__ float ld_f32(const void* p, size_t i) { return (float)((const T*)p)[i]; }
+
+// ------------------------------------------------------------------------------------------------ casts / packing
+template <typename T>
+__global__ void cast_to16_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n4, const float* scale_dev) {
+  const float sc = scale_dev ? scale_dev[0] : 1.0f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = *(const f32x4*)(in + i * 4);
+    typename Vec<T>::v4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = (T)(v[e] * sc);
+    *(typename Vec<T>::v4*)(out + i * 4) = w;
+  }
+}
+hipError_t launch_cast_f32_to16(int dtype, const float* in, void* out, size_t n, const float* scale_dev, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  if (n % 4) return hipErrorInvalidValue;
+  const size_t n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  if (dtype == DT_F16) hipLaunchKernelGGL(cast_to16_kernel<f16>, dim3(grid), dim3(256), 0, s, in, (f16*)out, n4, scale_dev);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(cast_to16_kernel<bf16>, dim3(grid), dim3(256), 0, s, in, (bf16*)out, n4, scale_dev);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+hipError_t launch_cast_any_to_f32(int in_dtype, const void* in, float* out, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  if (in_dtype == DT_F32) return hipMemcpyAsync(out, in, n * 4, hipMemcpyDeviceToDevice, s);
+  if (in_dtype == DT_F16) hipLaunchKernelGGL(cast_to_f32_kernel<f16>, dim3(grid), dim3(256), 0, s, (const f16*)in, out, n);
+  else if (in_dtype == DT_BF16) hipLaunchKernelGGL(cast_to_f32_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)in, out, n);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int rows, int cols, int ld_out) {
+  const size_t n = (size_t)rows * ld_out;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_out), c = (int)(i % ld_out);
+    out[i] = c < cols ? (T)w[(size_t)r * cols + c] : (T)0.f;
+  }
+}
+hipError_t launch_pack_weight(int dtype, const float* w, void* out, int rows, int cols, int ld_out, hipStream_t s) {
+  const size_t n = (size_t)rows * ld_out;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  if (dtype == DT_F16) hipLaunchKernelGGL(pack_weight_kernel<f16>, dim3(grid), dim3(256), 0, s, w, (f16*)out, rows, cols, ld_out);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(grid), dim3(256), 0, s, w, (bf16*)out, rows, cols, ld_out);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// tiled transpose through LDS: out[c][r] = w[r][c]
+template <typename T>
+__global__ void pack_weight_t_kernel(const float* __restrict__ w, T* __restrict__ out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < rows && c < cols) ? w[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (c < cols && r < rows) out[(size_t)c * rows + r] = (T)tile[tx][k];
+  }
+}
+hipError_t launch_pack_weight_t(int dtype, const float* w, void* out, int rows, int cols, hipStream_t s) {
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
+  if (dtype == DT_F16) hipLaunchKernelGGL(pack_weight_t_kernel<f16>, grid, block, 0, s, w, (f16*)out, rows, cols);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(pack_weight_t_kernel<bf16>, grid, block, 0, s, w, (bf16*)out, rows, cols);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_zero(void* p, size_t bytes, hipStream_t s) { return bytes ? hipMemsetAsync(p, 0, bytes, s) : hipSuccess; }
+
+// ------------------------------------------------------------------------------------------------ image side
+// patches[b*G2 + gy*G + gx][c*P*P + ky*P + kx] = image[b][c][gy*P+ky][gx*P+kx]     (conv1 as GEMM, clip/model.py:207)
+template <typename T, typename TI>
+__global__ void patchify_kernel(const TI* __restrict__ img, T* __restrict__ out, int B, int R, int P, int Kp) {
+  const int G = R / P, K = 3 * P * P;
+  const size_t n8 = (size_t)B * G * G * (Kp / 8);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const int cb = (int)(i % (Kp / 8));
+    const size_t row = i / (Kp / 8);
+    const int gx = (int)(row % G), gy = (int)((row / G) % G), b = (int)(row / ((size_t)G * G));
+    typename Vec<T>::v8 w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = cb * 8 + e;
+      float v = 0.f;
+      if (col < K) {
+        const int c = col / (P * P), ky = (col % (P * P)) / P, kx = col % P;
+        v = (float)img[(((size_t)b * 3 + c) * R + gy * P + ky) * R + gx * P + kx];
+      }
+      w[e] = (T)v;
+    }
+    *(typename Vec<T>::v8*)(out + row * Kp + cb * 8) = w;
+  }
+}
+template <typename T>
+static hipError_t patchify_t(const void* image, int image_dtype, T* out, int B, int R, int P, int Kp, hipStream_t s) {
+  const int G = R / P;
+  const size_t n8 = (size_t)B * G * G * (Kp / 8);
+  const int grid = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+  if (image_dtype == DT_F32) hipLaunchKernelGGL((patchify_kernel<T, float>), dim3(grid), dim3(256), 0, s, (const float*)image, out, B, R, P, Kp);
+  else if (image_dtype == DT_F16) hipLaunchKernelGGL((patchify_kernel<T, f16>), dim3(grid), dim3(256), 0, s, (const f16*)image, out, B, R, P, Kp);
+  else if (image_dtype == DT_BF16) hipLaunchKernelGGL((patchify_kernel<T, bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)image, out, B, R, P, Kp);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+hipError_t launch_patchify(int dtype, const void* image, int image_dtype, void* out, int B, int R, int P, int Kp, hipStream_t s) {
+  if (Kp % 8 || R % P) return hipErrorInvalidValue;
+  if (dtype == DT_F16) return patchify_t<f16>(image, image_dtype, (f16*)out, B, R, P, Kp, s);
+  if (dtype == DT_BF16) return patchify_t<bf16>(image, image_dtype, (bf16*)out, B, R, P, Kp, s);
+  return hipErrorInvalidValue;
+}
+
+// One wave per token row of x [B, 1+n+G2, d].  row 0: ln_pre(cls + pos[0]); rows 1..n: visual prompts, raw
+// (no positional embedding, no ln_pre: trainers/mvlpt.py:57-62, 416-437); others: ln_pre(patch + pos[1+i]).
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, const float* __restrict__ g,
+                                                              const float* __restrict__ bt, const float* __restrict__ vpt,
+                                                              int n_vpt, float* __restrict__ x, int B, int G2, int d) {
+  const int lane = threadIdx.x & 63;
+  const int L = 1 + n_vpt + G2;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (size_t)B * L) return;
+  const int b = (int)(row / L), i = (int)(row % L);
+  float* xo = x + row * d;
+  if (i >= 1 && i <= n_vpt) {
+    const float* src = vpt + (size_t)(i - 1) * d;
+    for (int c = lane * 4; c < d; c += 256) *(f32x4*)(xo + c) = *(const f32x4*)(src + c);
+    return;
+  }
+  const int pi = i == 0 ? 0 : i - n_vpt;                    // positional row
+  const float* src = i == 0 ? cls : pe + ((size_t)b * G2 + (pi - 1)) * d;
+  const float* pp = pos + (size_t)pi * d;
+  float s = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    const f32x4 v = *(const f32x4*)(src + c) + *(const f32x4*)(pp + c);
+    s += v[0] + v[1] + v[2] + v[3];
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    const f32x4 v = *(const f32x4*)(src + c) + *(const f32x4*)(pp + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float t = v[e] - mean; q += t * t; }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+  for (int c = lane * 4; c < d; c += 256) {
+    const f32x4 v = *(const f32x4*)(src + c) + *(const f32x4*)(pp + c);
+    const f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(bt + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e] + bb[e];
+    *(f32x4*)(xo + c) = o;
+  }
+}
+hipError_t launch_assemble_tokens(const float* patch_emb, const float* cls, const float* pos, const float* g, const float* b,
+                                  const float* vpt, int n_vpt, float* x, int B, int G2, int d, hipStream_t s) {
+  if (d % 4) return hipErrorInvalidValue;
+  const size_t rows = (size_t)B * (1 + n_vpt + G2);
+  hipLaunchKernelGGL(assemble_tokens_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, patch_emb, cls, pos, g, b, vpt,
+                     n_vpt, x, B, G2, d);
+  return hipGetLastError();
+}
+
+__global__ void overwrite_rows_kernel(const float* __restrict__ rows, int n, float* __restrict__ x, int B, int L, int d) {
+  const int d4 = d / 4;
+  const size_t total = (size_t)B * n * d4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % d4), j = (int)((i / d4) % n), b = (int)(i / ((size_t)d4 * n));
+    *(f32x4*)(x + ((size_t)b * L + 1 + j) * d + c * 4) = *(const f32x4*)(rows + (size_t)j * d + c * 4);
+  }
+}
+hipError_t launch_overwrite_rows(const float* rows, int n, float* x, int B, int L, int d, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const size_t total = (size_t)B * n * (d / 4);
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(overwrite_rows_kernel, dim3(grid), dim3(256), 0, s, rows, n, x, B, L, d);
+  return hipGetLastError();
+}
+
+// out[j,:] = inv_scale * sum_b dx32[b, row0+j, :]   (prompt rows are `expand`ed over the batch => sum over B);
+// optionally zero those rows afterwards (deep prompts overwrite the rows: upstream gradient is 0).
+template <typename T>
+__global__ void reduce_prompt_rows_kernel(float* __restrict__ dx32, T* __restrict__ dx16, int B, int L, int d, int row0,
+                                          int n, float* __restrict__ out, const float* scale_dev, int zero_after) {
+  const int j = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  const float inv = scale_dev ? scale_dev[1] : 1.0f;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const size_t o = ((size_t)b * L + row0 + j) * d + c;
+    acc += dx32[o];
+    if (zero_after) { dx32[o] = 0.f; if (dx16) dx16[o] = (T)0.f; }
+  }
+  out[(size_t)j * d + c] = acc * inv;
+}
+hipError_t launch_reduce_prompt_rows(int dtype, float* dx32, void* dx16, int B, int L, int d, int row0, int n, float* out,
+                                     const float* scale_dev, int zero_after, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  dim3 grid((d + 255) / 256, n), block(256);
+  if (dtype == DT_F16) hipLaunchKernelGGL(reduce_prompt_rows_kernel<f16>, grid, block, 0, s, dx32, (f16*)dx16, B, L, d, row0, n, out, scale_dev, zero_after);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(reduce_prompt_rows_kernel<bf16>, grid, block, 0, s, dx32, (bf16*)dx16, B, L, d, row0, n, out, scale_dev, zero_after);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ text side
+// x[c,i,:] = (layout[c,i] >= 0 ? fixed tokens : ctx row) + pos[i]      (trainers/mvlpt.py:439-515 + :107/:112)
+__global__ void assemble_prompts_kernel(const float* __restrict__ prefix, const float* __restrict__ suffix,
+                                        const float* __restrict__ ctx, int ctx_per_class, int n_ctx,
+                                        const int32_t* __restrict__ layout, const float* __restrict__ pos,
+                                        float* __restrict__ x, int C, int L, int d) {
+  const int d4 = d / 4;
+  const size_t total = (size_t)C * L * d4;
+  const int suf_len = L - 1 - n_ctx;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % d4);
+    const size_t tok = i / d4;
+    const int pos_i = (int)(tok % L), cls = (int)(tok / L);
+    const int e = layout[tok];
+    const float* src;
+    if (e == 0) src = prefix + (size_t)cls * d;
+    else if (e > 0) src = suffix + ((size_t)cls * suf_len + (e - 1)) * d;
+    else src = ctx + ((size_t)(ctx_per_class ? cls * n_ctx : 0) + (-e - 1)) * d;
+    *(f32x4*)(x + tok * d + c4 * 4) = *(const f32x4*)(src + c4 * 4) + *(const f32x4*)(pos + (size_t)pos_i * d + c4 * 4);
+  }
+}
+hipError_t launch_assemble_prompts(const float* prefix, const float* suffix, const float* ctx, int ctx_per_class, int n_ctx,
+                                   const int32_t* layout, const float* pos, float* x, int C, int L, int d, hipStream_t s) {
+  if (d % 4) return hipErrorInvalidValue;
+  const size_t total = (size_t)C * L * (d / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(assemble_prompts_kernel, dim3(grid), dim3(256), 0, s, prefix, suffix, ctx, ctx_per_class, n_ctx, layout,
+                     pos, x, C, L, d);
+  return hipGetLastError();
+}
+
+__global__ void build_ctx_pos_kernel(const int32_t* __restrict__ layout, int32_t* __restrict__ ctx_pos, int C, int L, int n_ctx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * L) return;
+  const int e = layout[i];
+  if (e < 0) ctx_pos[(i / L) * n_ctx + (-e - 1)] = i % L;
+}
+hipError_t launch_build_ctx_pos(const int32_t* layout, int32_t* ctx_pos, int C, int L, int n_ctx, hipStream_t s) {
+  if (n_ctx <= 0) return hipSuccess;
+  hipLaunchKernelGGL(build_ctx_pos_kernel, dim3((C * L + 255) / 256), dim3(256), 0, s, layout, ctx_pos, C, L, n_ctx);
+  return hipGetLastError();
+}
+__global__ void eot_rows_kernel(const int32_t* __restrict__ eot, int32_t* __restrict__ rows, int C, int L) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) rows[c] = c * L + eot[c];
+}
+hipError_t launch_eot_rows(const int32_t* eot, int32_t* rows, int C, int L, hipStream_t s) {
+  hipLaunchKernelGGL(eot_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, s, eot, rows, C, L);
+  return hipGetLastError();
+}
+
+// generic ctx: dctx[j,:] = inv * sum_c dx[c, pos(c,j), :]  (ctx is expanded over classes: trainers/mvlpt.py:455-456)
+// class-specific (CSC): dctx[c,j,:] = inv * dx[c, pos(c,j), :]
+__global__ void gather_ctx_grad_kernel(const float* __restrict__ dx, const int32_t* __restrict__ ctx_pos, int C, int L, int d,
+                                       int n_ctx, int per_class, float* __restrict__ dctx, const float* scale_dev) {
+  const int j = blockIdx.y;
+  const int c0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c0 >= d) return;
+  const float inv = scale_dev ? scale_dev[1] : 1.0f;
+  if (per_class) {
+    const int cls = blockIdx.z;
+    dctx[((size_t)cls * n_ctx + j) * d + c0] = inv * dx[((size_t)cls * L + ctx_pos[cls * n_ctx + j]) * d + c0];
+  } else {
+    float acc = 0.f;
+    for (int cls = 0; cls < C; ++cls) acc += dx[((size_t)cls * L + ctx_pos[cls * n_ctx + j]) * d + c0];
+    dctx[(size_t)j * d + c0] = acc * inv;
+  }
+}
+hipError_t launch_gather_ctx_grad(const float* dx, const int32_t* ctx_pos, int C, int L, int d, int n_ctx, int per_class,
+                                  float* dctx, const float* scale_dev, hipStream_t s) {
+  if (n_ctx <= 0) return hipSuccess;
+  dim3 grid((d + 255) / 256, n_ctx, per_class ? C : 1), block(256);
+  hipLaunchKernelGGL(gather_ctx_grad_kernel, grid, block, 0, s, dx, ctx_pos, C, L, d, n_ctx, per_class, dctx, scale_dev);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ gradient scaling
+// The backward is linear in the incoming gradient, so it is run on  2^k * dfeat  to keep 16-bit activation
+// gradients in range (the reference's fp16 mode has no GradScaler, trainers/mvlpt.py:873,927-932, and simply
+// underflows); prompt gradients are multiplied by 2^-k when they are reduced.  Single block, deterministic.
+__global__ __launch_bounds__(1024) void grad_scale_kernel(const float* __restrict__ v, size_t n, float target, float* scale_dev) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(v[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    float sc = 1.0f;
+    if (m > 0.f && isfinite(m)) {
+      int e; frexpf(m, &e);                      // m = f * 2^e, f in [0.5, 1)
+      int et; frexpf(target, &et);
+      int k = et - e; k = k > 60 ? 60 : (k < -60 ? -60 : k);
+      sc = ldexpf(1.0f, k);
+    }
+    scale_dev[0] = sc;
+    scale_dev[1] = 1.0f / sc;
+  }
+}
+hipError_t launch_grad_scale(const float* v, size_t n, float target, float* scale_dev, hipStream_t s) {
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1024), 0, s, v, n, target, scale_dev);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ head (fp32)
+// xn = x / ||x||  (no epsilon: trainers/mvlpt.py:550-551)
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ xn,
+                                                             float* __restrict__ norm, int rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = x + (size_t)row * d;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) s += p[c] * p[c];
+  const float nm = sqrtf(wave_sum(s));
+  for (int c = lane; c < d; c += 64) xn[(size_t)row * d + c] = p[c] / nm;
+  if (lane == 0) norm[row] = nm;
+}
+hipError_t launch_normalize_rows(const float* x, float* xn, float* norm, int rows, int d, hipStream_t s) {
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, xn, norm, rows, d);
+  return hipGetLastError();
+}
+
+// logits[b,c] = (scale * imn[b,:]) . txn[c,:]  * [lo[b] <= c < hi[b]]      (trainers/mvlpt.py:553-554, 573-581)
+__global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ imn, const float* __restrict__ txn, float scale,
+                                                     const int32_t* __restrict__ lo, const int32_t* __restrict__ hi,
+                                                     float* __restrict__ logits, int B, int C, int e) {
+  extern __shared__ float simg[];
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < e; i += 256) simg[i] = scale * imn[(size_t)b * e + i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = blockIdx.y * 4 + wave; c < C; c += gridDim.y * 4) {
+    const float* t = txn + (size_t)c * e;
+    float s = 0.f;
+    for (int i = lane; i < e; i += 64) s += simg[i] * t[i];
+    s = wave_sum(s);
+    if (lane == 0) {
+      if (lo && !(c >= lo[b] && c < hi[b])) s *= 0.0f;   // multiplicative 0/1 mask, as in the reference
+      logits[(size_t)b * C + c] = s;
+    }
+  }
+}
+hipError_t launch_logits(const float* imn, const float* txn, float scale, const int32_t* lo, const int32_t* hi, float* logits,
+                         int B, int C, int e, hipStream_t s) {
+  int gy = (C + 3) / 4; gy = gy > 64 ? 64 : gy;
+  hipLaunchKernelGGL(logits_kernel, dim3(B, gy), dim3(256), e * sizeof(float), s, imn, txn, scale, lo, hi, logits, B, C, e);
+  return hipGetLastError();
+}
+
+// F.cross_entropy(logits, label), mean over the batch (trainers/mvlpt.py:931); int64 class ids or fp32
+// probability rows.  One wave per row; the mean is a second, single-wave deterministic pass.
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const void* __restrict__ labels,
+                                                      int label_kind, int B, int C, float* __restrict__ row_loss,
+                                                      float* __restrict__ dlogits, float* __restrict__ row_correct) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* z = logits + (size_t)b * C;
+  float mx = -INFINITY; int arg = 0;
+  for (int c = lane; c < C; c += 64) if (z[c] > mx) { mx = z[c]; arg = c; }
+  // arg-max with lowest-index tie break across the wave
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o, 64); const int oa = __shfl_xor(arg, o, 64);
+    if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
+  }
+  float se = 0.f;
+  for (int c = lane; c < C; c += 64) se += __expf(z[c] - mx);
+  se = wave_sum(se);
+  const float lse = mx + __logf(se);
+  float loss = 0.f, ysum = 0.f; int target = -1;
+  if (label_kind == 0) {
+    target = (int)((const int64_t*)labels)[b];
+    ysum = 1.0f;
+    loss = lse - z[target];
+  } else {
+    const float* y = (const float*)labels + (size_t)b * C;
+    float ymx = -INFINITY; int yarg = 0;
+    for (int c = lane; c < C; c += 64) {
+      ysum += y[c]; loss += y[c] * (lse - z[c]);
+      if (y[c] > ymx) { ymx = y[c]; yarg = c; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(ymx, o, 64); const int oa = __shfl_xor(yarg, o, 64);
+      if (om > ymx || (om == ymx && oa < yarg)) { ymx = om; yarg = oa; }
+    }
+    ysum = wave_sum(ysum); loss = wave_sum(loss);
+    target = yarg;                                 // training accuracy uses argmax(label), trainers/mvlpt.py:935-936
+  }
+  if (lane == 0) { row_loss[b] = loss; if (row_correct) row_correct[b] = arg == target ? 1.f : 0.f; }
+  if (dlogits) {
+    const float invB = 1.0f / (float)B;
+    for (int c = lane; c < C; c += 64) {
+      const float p = __expf(z[c] - lse);
+      const float y = label_kind == 0 ? (c == target ? 1.f : 0.f) : ((const float*)labels)[(size_t)b * C + c];
+      dlogits[(size_t)b * C + c] = (p * ysum - y) * invB;
+    }
+  }
+}
+__global__ void ce_mean_kernel(const float* __restrict__ row_loss, const float* __restrict__ row_correct, int B,
+                               float* __restrict__ loss, float* __restrict__ ncorrect) {
+  const int lane = threadIdx.x;
+  float s = 0.f, k = 0.f;
+  for (int b = lane; b < B; b += 64) { s += row_loss[b]; if (row_correct) k += row_correct[b]; }
+  s = wave_sum(s); k = wave_sum(k);
+  if (lane == 0) { loss[0] = s / (float)B; if (ncorrect) ncorrect[0] = k; }
+}
+hipError_t launch_cross_entropy(const float* logits, const void* labels, int label_kind, int B, int C, float* row_loss,
+                                float* loss, float* dlogits, float* ncorrect, hipStream_t s) {
+  float* row_correct = ncorrect ? row_loss + B : nullptr;   // caller provides 2*B floats of scratch
+  hipLaunchKernelGGL(ce_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, labels, label_kind, B, C, row_loss, dlogits, row_correct);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(64), 0, s, row_loss, row_correct, B, loss, ncorrect);
+  return hipGetLastError();
+}
+
+// d imn = scale * (dlogits*mask) txn ; d txn = scale * (dlogits*mask)^T imn ; then through x/||x||.
+__global__ __launch_bounds__(256) void logits_bwd_img_kernel(const float* __restrict__ dl, const float* __restrict__ imn,
+                                                             const float* __restrict__ txn, const float* __restrict__ inorm,
+                                                             float scale, const int32_t* __restrict__ lo,
+                                                             const int32_t* __restrict__ hi, float* __restrict__ dimg,
+                                                             int B, int C, int e) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const int c_lo = lo ? lo[b] : 0, c_hi = lo ? hi[b] : C;
+  float dot = 0.f;
+  // each thread owns columns i = tid, tid+256, ... ; keep d(imn) in registers (e <= 1024)
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = c_lo; c < c_hi; ++c) {
+    const float w = scale * dl[(size_t)b * C + c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = threadIdx.x + k * 256; if (i < e) g[k] += w * txn[(size_t)c * e + i]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int i = threadIdx.x + k * 256; if (i < e) dot += g[k] * imn[(size_t)b * e + i]; }
+  dot = wave_sum(dot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  dot = red[0] + red[1] + red[2] + red[3];
+  const float inv = 1.0f / inorm[b];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < e) dimg[(size_t)b * e + i] = (g[k] - imn[(size_t)b * e + i] * dot) * inv;
+  }
+}
+__global__ __launch_bounds__(256) void logits_bwd_txt_kernel(const float* __restrict__ dl, const float* __restrict__ imn,
+                                                             const float* __restrict__ txn, const float* __restrict__ tnorm,
+                                                             float scale, const int32_t* __restrict__ lo,
+                                                             const int32_t* __restrict__ hi, float* __restrict__ dtxt,
+                                                             int B, int C, int e) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; ++b) {
+    if (lo && !(c >= lo[b] && c < hi[b])) continue;
+    const float w = scale * dl[(size_t)b * C + c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = threadIdx.x + k * 256; if (i < e) g[k] += w * imn[(size_t)b * e + i]; }
+  }
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int i = threadIdx.x + k * 256; if (i < e) dot += g[k] * txn[(size_t)c * e + i]; }
+  dot = wave_sum(dot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  dot = red[0] + red[1] + red[2] + red[3];
+  const float inv = 1.0f / tnorm[c];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < e) dtxt[(size_t)c * e + i] = (g[k] - txn[(size_t)c * e + i] * dot) * inv;
+  }
+}
+hipError_t launch_logits_bwd(const float* dlogits, const float* imn, const float* txn, const float* inorm, const float* tnorm,
+                             float scale, const int32_t* lo, const int32_t* hi, float* dimg, float* dtxt, int B, int C, int e,
+                             hipStream_t s) {
+  if (e > 1024) return hipErrorInvalidValue;
+  if (dimg) hipLaunchKernelGGL(logits_bwd_img_kernel, dim3(B), dim3(256), 0, s, dlogits, imn, txn, inorm, scale, lo, hi, dimg, B, C, e);
+  if (dtxt) hipLaunchKernelGGL(logits_bwd_txt_kernel, dim3(C), dim3(256), 0, s, dlogits, imn, txn, tnorm, scale, lo, hi, dtxt, B, C, e);
+  return hipGetLastError();
+}
+
+}  // namespace mvlpt

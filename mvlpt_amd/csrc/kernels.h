@@ -1,0 +1,103 @@
+// Launcher declarations for the hand-written gfx950 kernels (gemm.hip, norm.hip, attention.hip, glue.hip).
+// Every launcher only enqueues on the given stream; no hidden synchronisation.
+#pragma once
+#include "common.h"
+
+namespace mvlpt {
+
+// ---------------------------------------------------------------- GEMM  C = A * Bt^T (+ epilogue)
+enum GemmEpi {
+  EPI_STORE16 = 0,  // out16 = acc (+bias)
+  EPI_GELU = 1,     // u = acc+bias ; out2 (optional, 16-bit) = u ; out16 = QuickGELU(u)
+  EPI_RESID32 = 2,  // out32 = acc + bias + resid32          (fp32 residual stream, may alias out)
+  EPI_GELUBWD = 3,  // out16 = acc * QuickGELU'(aux16)       (aux = saved pre-activation u)
+  EPI_STORE32 = 4,  // out32 = acc (+bias)
+};
+struct GemmArgs {
+  const void* A;       // [M,K] 16-bit
+  const void* Bt;      // [N,K] 16-bit
+  int M, N, K;
+  const float* bias;   // [N] or null
+  const void* aux;     // [M,N] 16-bit (EPI_GELUBWD)
+  const float* resid;  // [M,N] fp32   (EPI_RESID32)
+  void* out;           // [M,N]
+  void* out2;          // [M,N] 16-bit, optional (EPI_GELU)
+};
+hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s);
+
+// ---------------------------------------------------------------- LayerNorm (fp32 statistics)
+// Input row r is read at  x + in_row(r) * d  with in_row(r) = row_idx ? row_idx[r] : r * row_mul.
+struct LnFwdArgs {
+  const float* x; const int32_t* row_idx; int row_mul;
+  const float* gamma; const float* beta;
+  void* y;          // [rows,d] contiguous, 16-bit (out_dtype = compute dtype) or fp32 (out_dtype = DT_F32)
+  int rows, d;
+};
+hipError_t launch_ln_fwd(int out_dtype, const LnFwdArgs& a, hipStream_t s);
+
+struct LnBwdArgs {
+  const void* dy;        // [rows,d] contiguous 16-bit
+  const float* x; const int32_t* row_idx; int row_mul;   // LN input rows (same mapping as forward)
+  const float* gamma;
+  const float* resid;    // fp32, same row mapping as x, or null:  out32 = resid + dx
+  float* out32;          // fp32, same row mapping as x (may alias resid)
+  void* out16;           // optional 16-bit copy, same row mapping
+  int rows, d;
+};
+hipError_t launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- attention (head_dim 64, L <= 256)
+// qkv: [N*L, 3*d] 16-bit, token = n*L + i, columns [q | k | v], head h at h*64 inside each third.
+struct AttnArgs {
+  const void* qkv; void* out /*[N*L,d]*/; float* lse /*[N*H*L] or null*/;
+  int N, L, H; int causal;
+};
+hipError_t launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s);
+struct AttnBwdArgs {
+  const void* qkv; const void* out; const void* dout; const float* lse;
+  float* delta /*[N*H*L] scratch*/; void* dqkv /*[N*L,3d]*/;
+  int N, L, H; int causal;
+};
+hipError_t launch_attn_bwd(int dtype, const AttnBwdArgs& a, hipStream_t s);
+int attn_max_len();
+
+// ---------------------------------------------------------------- glue
+hipError_t launch_cast_f32_to16(int dtype, const float* in, void* out, size_t n, const float* scale_dev, hipStream_t s);
+hipError_t launch_cast_any_to_f32(int in_dtype, const void* in, float* out, size_t n, hipStream_t s);
+// W [rows, cols] (fp32) -> out16 [rows, ld_out] zero padded (cols <= ld_out)
+hipError_t launch_pack_weight(int dtype, const float* w, void* out, int rows, int cols, int ld_out, hipStream_t s);
+// W [rows, cols] (fp32) -> out16 [cols, rows] (transposed)
+hipError_t launch_pack_weight_t(int dtype, const float* w, void* out, int rows, int cols, hipStream_t s);
+// image [B,3,R,R] (fp32 / f16 / bf16) -> patches16 [B*g*g, Kp], column order (c,ky,kx), zero padded to Kp
+hipError_t launch_patchify(int dtype, const void* image, int image_dtype, void* out, int B, int R, int P, int Kp, hipStream_t s);
+// tokens: row0 = LN(cls + pos0); rows 1..n = vpt; rest = LN(patch + pos)   (trainers/mvlpt.py:56-62)
+hipError_t launch_assemble_tokens(const float* patch_emb, const float* cls, const float* pos, const float* g, const float* b,
+                                  const float* vpt, int n_vpt, float* x, int B, int G2, int d, hipStream_t s);
+// x[b, 1+j, :] = rows[j, :]   (deep prompt overwrite, trainers/mvlpt.py:78-82)
+hipError_t launch_overwrite_rows(const float* rows, int n, float* x, int B, int L, int d, hipStream_t s);
+// prompts (forward_coop + positional embedding, trainers/mvlpt.py:439-515, 107/112)
+hipError_t launch_assemble_prompts(const float* prefix, const float* suffix, const float* ctx, int ctx_per_class, int n_ctx,
+                                   const int32_t* layout, const float* pos, float* x, int C, int L, int d, hipStream_t s);
+hipError_t launch_build_ctx_pos(const int32_t* layout, int32_t* ctx_pos, int C, int L, int n_ctx, hipStream_t s);
+hipError_t launch_eot_rows(const int32_t* eot, int32_t* rows, int C, int L, hipStream_t s);
+// out[j,:] = inv_scale * sum_b dx[b, row0+j, :]; optionally zero those rows of dx32/dx16 afterwards
+hipError_t launch_reduce_prompt_rows(int dtype, float* dx32, void* dx16, int B, int L, int d, int row0, int n, float* out,
+                                     const float* scale_dev, int zero_after, hipStream_t s);
+// dctx (generic) [n,d] = inv_scale * sum_c dx[c, ctx_pos[c,j], :]  or (per class) [C,n,d]
+hipError_t launch_gather_ctx_grad(const float* dx, const int32_t* ctx_pos, int C, int L, int d, int n_ctx, int per_class,
+                                  float* dctx, const float* scale_dev, hipStream_t s);
+// scale_dev[0] = 2^k with amax(|v|)*2^k ~ target ; scale_dev[1] = 1/scale_dev[0]
+hipError_t launch_grad_scale(const float* v, size_t n, float target, float* scale_dev, hipStream_t s);
+hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);
+
+// ---------------------------------------------------------------- head: cosine logits + cross-entropy (fp32)
+hipError_t launch_normalize_rows(const float* x, float* xn, float* norm, int rows, int d, hipStream_t s);
+hipError_t launch_logits(const float* imn, const float* txn, float scale, const int32_t* lo, const int32_t* hi,
+                         float* logits, int B, int C, int e, hipStream_t s);
+hipError_t launch_cross_entropy(const float* logits, const void* labels, int label_kind, int B, int C, float* row_loss,
+                                float* loss, float* dlogits, float* ncorrect, hipStream_t s);
+hipError_t launch_logits_bwd(const float* dlogits, const float* imn, const float* txn, const float* inorm, const float* tnorm,
+                             float scale, const int32_t* lo, const int32_t* hi, float* dimg, float* dtxt,
+                             int B, int C, int e, hipStream_t s);
+
+}  // namespace mvlpt

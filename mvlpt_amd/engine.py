@@ -1,0 +1,253 @@
+"""Thin torch-facing wrapper over the C ABI: device pointers + the current HIP stream in, tensors out.
+
+PyTorch is plumbing here (device memory, streams); all compute is in libmvlpt_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import DT_BF16, DT_F16, DT_F32, lib
+from .weights import ClipArch, arch_from_state_dict
+
+_TORCH2DT = {torch.float32: DT_F32, torch.float16: DT_F16, torch.bfloat16: DT_BF16}
+_DT2TORCH = {DT_F16: torch.float16, DT_BF16: torch.bfloat16, DT_F32: torch.float32}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor: mvlpt_amd has no CPU path")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+class Engine:
+    """One handle per process per GPU (include/mvlpt_hip.h)."""
+
+    def __init__(self, arch: ClipArch, compute_dtype: str = "fp16", device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("mvlpt_amd.Engine needs a HIP device (no CPU fallback)")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.arch = arch
+        self.dt = {"fp16": DT_F16, "bf16": DT_BF16}[compute_dtype]
+        self.torch_dtype = _DT2TORCH[self.dt]
+        a = _lib.MvlptArch(arch.image_resolution, arch.vision_patch_size, arch.vision_width, arch.vision_layers,
+                           arch.vision_heads, arch.context_length, arch.transformer_width, arch.transformer_layers,
+                           arch.transformer_heads, arch.embed_dim, self.dt)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mvlpt_create(C.byref(a), C.byref(h)), None, "mvlpt_create")
+        self.h = h
+        self._keep: List[torch.Tensor] = []     # tensors the library reads asynchronously / later
+        self._img_state = None
+        self._txt_state = None
+        self._head_state = None
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "h", None):
+            lib.mvlpt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @classmethod
+    def from_state_dict(cls, sd: Dict[str, torch.Tensor], compute_dtype: str = "fp16", device=None,
+                        arch: Optional[ClipArch] = None) -> "Engine":
+        eng = cls(arch or arch_from_state_dict(sd), compute_dtype, device)
+        eng.load_frozen(sd)
+        return eng
+
+    def load_frozen(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Pack the frozen CLIP tensors (keys of clip.model.CLIP.state_dict())."""
+        with torch.cuda.device(self.device):
+            for name, t in sd.items():
+                if name in ("logit_scale", "token_embedding.weight", "input_resolution", "context_length", "vocab_size"):
+                    continue
+                if t.dtype not in _TORCH2DT:
+                    t = t.float()
+                tg = t.to(self.device).contiguous()
+                shape = (C.c_int64 * max(tg.dim(), 1))(*tg.shape)
+                _lib.check(lib.mvlpt_load_frozen(self.h, name.encode(), _ptr(tg), _TORCH2DT[tg.dtype], shape, tg.dim(),
+                                                 _stream()), self.h, f"load_frozen({name})")
+                torch.cuda.current_stream().synchronize()   # tg may be freed right after
+            _lib.check(lib.mvlpt_frozen_ready(self.h), self.h, "frozen_ready")
+
+    # ------------------------------------------------------------------ towers
+    def image_fwd(self, image: torch.Tensor, vpt: Optional[torch.Tensor] = None, vpt_deep: Optional[torch.Tensor] = None,
+                  save_for_bwd: bool = False) -> torch.Tensor:
+        if image.dtype not in _TORCH2DT:
+            image = image.float()
+        image = image.contiguous()
+        if not image.is_cuda:
+            raise RuntimeError("image must be on the GPU")
+        B = image.shape[0]
+        n_vpt = n_deep = 0
+        if vpt is not None:
+            vpt = _req(vpt, torch.float32, "vpt").reshape(-1, self.arch.vision_width)
+            n_vpt = vpt.shape[0]
+        if vpt_deep is not None:
+            vpt_deep = _req(vpt_deep, torch.float32, "vpt_deep")
+            n_deep = vpt_deep.shape[0]
+        feat = torch.empty(B, self.arch.embed_dim, device=image.device, dtype=torch.float32)
+        _lib.check(lib.mvlpt_image_fwd(self.h, _ptr(image), _TORCH2DT[image.dtype], _ptr(vpt), _ptr(vpt_deep), n_vpt, n_deep, B,
+                                       _ptr(feat), int(save_for_bwd), _stream()), self.h, "image_fwd")
+        self._img_state = (n_vpt, n_deep, B) if save_for_bwd else None
+        return feat
+
+    def image_bwd(self, dfeat: torch.Tensor) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+        if self._img_state is None:
+            raise RuntimeError("image_bwd without image_fwd(save_for_bwd=True)")
+        n_vpt, n_deep, B = self._img_state
+        dfeat = _req(dfeat, torch.float32, "dfeat")
+        dv = self.arch.vision_width
+        dvpt = torch.empty(n_vpt, dv, device=dfeat.device, dtype=torch.float32) if n_vpt else None
+        ddeep = torch.empty(n_deep, n_vpt, dv, device=dfeat.device, dtype=torch.float32) if n_deep else None
+        _lib.check(lib.mvlpt_image_bwd(self.h, _ptr(dfeat), _ptr(dvpt), _ptr(ddeep), _stream()), self.h, "image_bwd")
+        return dvpt, ddeep
+
+    def text_fwd(self, prefix: torch.Tensor, suffix: torch.Tensor, ctx: Optional[torch.Tensor], layout: torch.Tensor,
+                 eot: torch.Tensor, save_for_bwd: bool = False) -> torch.Tensor:
+        prefix = _req(prefix, torch.float32, "token_prefix")
+        suffix = _req(suffix, torch.float32, "token_suffix")
+        layout = _req(layout, torch.int32, "layout")
+        eot = _req(eot, torch.int32, "eot")
+        Cn, L = layout.shape
+        per_class, n_ctx = 0, 0
+        if ctx is not None:
+            ctx = _req(ctx, torch.float32, "ctx")
+            per_class = int(ctx.dim() == 3)
+            n_ctx = ctx.shape[-2]
+        feat = torch.empty(Cn, self.arch.embed_dim, device=prefix.device, dtype=torch.float32)
+        _lib.check(lib.mvlpt_text_fwd(self.h, _ptr(prefix), _ptr(suffix), _ptr(ctx), per_class, n_ctx, _ptr(layout), _ptr(eot),
+                                      Cn, L, _ptr(feat), int(save_for_bwd), _stream()), self.h, "text_fwd")
+        self._txt_state = (tuple(ctx.shape) if ctx is not None else None, layout, eot) if save_for_bwd else None
+        return feat
+
+    def text_bwd(self, dfeat: torch.Tensor) -> torch.Tensor:
+        if self._txt_state is None or self._txt_state[0] is None:
+            raise RuntimeError("text_bwd without text_fwd(save_for_bwd=True) with context tokens")
+        dfeat = _req(dfeat, torch.float32, "dfeat")
+        dctx = torch.empty(self._txt_state[0], device=dfeat.device, dtype=torch.float32)
+        _lib.check(lib.mvlpt_text_bwd(self.h, _ptr(dfeat), _ptr(dctx), _stream()), self.h, "text_bwd")
+        return dctx
+
+    # ------------------------------------------------------------------ head
+    def logits_fwd(self, img_feat, txt_feat, logit_scale_exp: float, task_lo=None, task_hi=None) -> torch.Tensor:
+        img_feat = _req(img_feat, torch.float32, "img_feat")
+        txt_feat = _req(txt_feat, torch.float32, "txt_feat")
+        if task_lo is not None:
+            task_lo = _req(task_lo, torch.int32, "task_lo")
+            task_hi = _req(task_hi, torch.int32, "task_hi")
+        B, Cn = img_feat.shape[0], txt_feat.shape[0]
+        logits = torch.empty(B, Cn, device=img_feat.device, dtype=torch.float32)
+        _lib.check(lib.mvlpt_logits_fwd(self.h, _ptr(img_feat), _ptr(txt_feat), float(logit_scale_exp), _ptr(task_lo),
+                                        _ptr(task_hi), B, Cn, _ptr(logits), _stream()), self.h, "logits_fwd")
+        self._head_state = (task_lo, task_hi, B, Cn)   # keep the mask tensors alive until logits_bwd
+        return logits
+
+    def logits_bwd(self, dlogits, need_img: bool = True, need_txt: bool = True):
+        if self._head_state is None:
+            raise RuntimeError("logits_bwd without logits_fwd")
+        _, _, B, Cn = self._head_state
+        dlogits = _req(dlogits, torch.float32, "dlogits")
+        e = self.arch.embed_dim
+        dimg = torch.empty(B, e, device=dlogits.device, dtype=torch.float32) if need_img else None
+        dtxt = torch.empty(Cn, e, device=dlogits.device, dtype=torch.float32) if need_txt else None
+        _lib.check(lib.mvlpt_logits_bwd(self.h, _ptr(dlogits), _ptr(dimg), _ptr(dtxt), _stream()), self.h, "logits_bwd")
+        return dimg, dtxt
+
+    def cross_entropy(self, logits, label, need_grad: bool = True):
+        """Returns (loss[1], dlogits or None, ncorrect[1]) — device tensors, no host sync."""
+        logits = _req(logits, torch.float32, "logits")
+        B, Cn = logits.shape
+        if label.dtype in (torch.int64, torch.int32, torch.int16, torch.uint8):
+            label = _req(label, torch.int64, "label")
+            kind = _lib.LABEL_INT64
+            if label.shape != (B,):
+                raise ValueError("integer labels must have shape [B]")
+        else:
+            label = _req(label, torch.float32, "label")
+            kind = _lib.LABEL_PROB_F32
+            if label.shape != (B, Cn):
+                raise ValueError("probability labels must have shape [B, C]")
+        loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+        nc = torch.empty(1, device=logits.device, dtype=torch.float32)
+        dl = torch.empty_like(logits) if need_grad else None
+        _lib.check(lib.mvlpt_cross_entropy(self.h, _ptr(logits), _ptr(label), kind, B, Cn, _ptr(loss), _ptr(dl), _ptr(nc),
+                                           _stream()), self.h, "cross_entropy")
+        return loss, dl, nc
+
+    # ------------------------------------------------------------------ profiling
+    def profile_begin(self):
+        _lib.check(lib.mvlpt_profile_begin(self.h), self.h, "profile_begin")
+
+    def profile_end(self) -> Dict[str, dict]:
+        arr = (_lib.MvlptKernelStat * 16)()
+        n = lib.mvlpt_profile_end(self.h, arr, 16)
+        if n < 0:
+            raise RuntimeError("profile_end failed")
+        return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes)
+                for i in range(n)}
+
+
+# ---------------------------------------------------------------------- kernel-level ops (parity tests)
+def op_gemm(A, Bt, epi=_lib.EPI_STORE16, bias=None, aux=None, resid=None, out2=False):
+    dt = _TORCH2DT[A.dtype]
+    M, K = A.shape
+    N = Bt.shape[0]
+    out_dtype = torch.float32 if epi in (_lib.EPI_RESID32, _lib.EPI_STORE32) else A.dtype
+    out = torch.empty(M, N, device=A.device, dtype=out_dtype)
+    o2 = torch.empty(M, N, device=A.device, dtype=A.dtype) if out2 else None
+    _lib.check(lib.mvlpt_op_gemm(dt, epi, _ptr(A.contiguous()), _ptr(Bt.contiguous()), M, N, K, _ptr(bias), _ptr(aux),
+                                 _ptr(resid), _ptr(out), _ptr(o2), _stream()), None, "op_gemm")
+    return (out, o2) if out2 else out
+
+
+def op_layernorm_fwd(x, gamma, beta, out_dtype):
+    rows, d = x.shape
+    y = torch.empty(rows, d, device=x.device, dtype=out_dtype)
+    _lib.check(lib.mvlpt_op_layernorm_fwd(_TORCH2DT[out_dtype], _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), rows, d, _stream()),
+               None, "op_layernorm_fwd")
+    return y
+
+
+def op_layernorm_bwd(dy, x, gamma, resid=None, want16=True):
+    rows, d = x.shape
+    out32 = torch.empty(rows, d, device=x.device, dtype=torch.float32)
+    out16 = torch.empty(rows, d, device=x.device, dtype=dy.dtype) if want16 else None
+    _lib.check(lib.mvlpt_op_layernorm_bwd(_TORCH2DT[dy.dtype], _ptr(dy), _ptr(x), _ptr(gamma), _ptr(resid), _ptr(out32),
+                                          _ptr(out16), rows, d, _stream()), None, "op_layernorm_bwd")
+    return out32, out16
+
+
+def op_attention_fwd(qkv, N, L, H, causal, want_lse=True):
+    out = torch.empty(N * L, H * 64, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(N * H * L, device=qkv.device, dtype=torch.float32) if want_lse else None
+    _lib.check(lib.mvlpt_op_attention_fwd(_TORCH2DT[qkv.dtype], _ptr(qkv), _ptr(out), _ptr(lse), N, L, H, int(causal), _stream()),
+               None, "op_attention_fwd")
+    return out, lse
+
+
+def op_attention_bwd(qkv, out, dout, lse, N, L, H, causal):
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(N * H * L, device=qkv.device, dtype=torch.float32)
+    _lib.check(lib.mvlpt_op_attention_bwd(_TORCH2DT[qkv.dtype], _ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(delta),
+                                          _ptr(dqkv), N, L, H, int(causal), _stream()), None, "op_attention_bwd")
+    return dqkv

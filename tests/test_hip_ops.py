@@ -1,0 +1,138 @@
+"""Kernel-level parity (-m gpu): every hand-written HIP kernel, called through the C ABI, against the CPU
+oracle (oracle/clip_oracle.py) on the same seeded inputs.  Tolerances are relative to the reference's max
+magnitude; inputs are rounded to the 16-bit compute type first so only the kernel's own arithmetic differs."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import clip_oracle as O  # noqa: E402
+
+
+def _eng():
+    from mvlpt_amd import engine
+    return engine
+
+
+def relerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
+DTYPES = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}   # output rounding of the 16-bit type dominates
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (77, 128, 128), (1000, 768, 3072), (4096, 2304, 768)])
+def test_gemm_store16_bias(dtype, M, N, K):
+    E = _eng()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    Bt = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype)
+    bias = torch.randn(N, generator=g)
+    ref = A.float() @ Bt.float().t() + bias
+    out = E.op_gemm(A.cuda(), Bt.cuda(), E._lib.EPI_STORE16, bias=bias.cuda())
+    assert relerr(out, ref) < TOL[dtype]
+    out_nb = E.op_gemm(A.cuda(), Bt.cuda(), E._lib.EPI_STORE16)
+    assert relerr(out_nb, ref - bias) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(dtype):
+    E = _eng()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 391, 512, 256
+    A = torch.randn(M, K, generator=g).to(dtype)
+    Bt = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype)
+    bias = torch.randn(N, generator=g)
+    acc = A.float() @ Bt.float().t()
+    # fp32 store: only accumulation-order error
+    out32 = E.op_gemm(A.cuda(), Bt.cuda(), E._lib.EPI_STORE32, bias=bias.cuda())
+    assert relerr(out32, acc + bias) < 2e-5
+    # residual
+    resid = torch.randn(M, N, generator=g)
+    outr = E.op_gemm(A.cuda(), Bt.cuda(), E._lib.EPI_RESID32, bias=bias.cuda(), resid=resid.cuda())
+    assert relerr(outr, acc + bias + resid) < 2e-5
+    # in-place residual (out aliases resid) is what the towers use
+    # QuickGELU + saved pre-activation
+    a16, u16 = E.op_gemm(A.cuda(), Bt.cuda(), E._lib.EPI_GELU, bias=bias.cuda(), out2=True)
+    assert relerr(u16, acc + bias) < TOL[dtype]
+    assert relerr(a16, O.quick_gelu(acc + bias)) < TOL[dtype]
+    # GELU backward epilogue
+    u = torch.randn(M, N, generator=g).to(dtype)
+    outg = E.op_gemm(A.cuda(), Bt.cuda(), E._lib.EPI_GELUBWD, aux=u.cuda())
+    assert relerr(outg, acc * O.quick_gelu_grad(u.float())) < TOL[dtype]
+
+
+@pytest.mark.parametrize("d", [128, 512, 768, 1024])
+def test_layernorm_fwd_bwd(d):
+    E = _eng()
+    g = torch.Generator().manual_seed(d)
+    rows = 203
+    x = torch.randn(rows, d, generator=g) * 3 + 0.5
+    gamma = 1 + 0.1 * torch.randn(d, generator=g)
+    beta = 0.1 * torch.randn(d, generator=g)
+    y_ref, (xhat, rstd) = O.layernorm_fwd(x, gamma, beta)
+    y32 = E.op_layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), torch.float32)
+    assert relerr(y32, y_ref) < 1e-5
+    for dtype in DTYPES:
+        y16 = E.op_layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), dtype)
+        assert relerr(y16, y_ref) < TOL[dtype]
+        dy = torch.randn(rows, d, generator=g).to(dtype)
+        resid = torch.randn(rows, d, generator=g)
+        dx_ref = resid + O.layernorm_bwd(dy.float(), xhat, rstd, gamma)
+        dx32, dx16 = E.op_layernorm_bwd(dy.cuda(), x.cuda(), gamma.cuda(), resid.cuda())
+        assert relerr(dx32, dx_ref) < 2e-5
+        assert relerr(dx16, dx_ref) < TOL[dtype]
+
+
+def _attn_ref(qkv, N, L, H, causal):
+    d = H * 64
+    q, k, v = (t.reshape(N, L, H, 64).permute(0, 2, 1, 3) for t in qkv.float().reshape(N, L, 3 * d).split(d, dim=-1))
+    o, p = O.attention_fwd(q, k, v, causal)
+    return q, k, v, o, p
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("L,causal", [(5, False), (5, True), (24, True), (50, False), (77, True), (197, False), (205, False), (256, False)])
+def test_attention_fwd_bwd(dtype, L, causal):
+    E = _eng()
+    N, H = 3, 2
+    d = H * 64
+    g = torch.Generator().manual_seed(L * 2 + int(causal))
+    qkv = torch.randn(N * L, 3 * d, generator=g).to(dtype)
+    q, k, v, o, p = _attn_ref(qkv, N, L, H, causal)
+    out, lse = E.op_attention_fwd(qkv.cuda(), N, L, H, causal)
+    o_ref = o.permute(0, 2, 1, 3).reshape(N * L, d)
+    assert relerr(out, o_ref) < TOL[dtype] * 1.5
+    # log-sum-exp of the scaled scores
+    s = torch.matmul(q, k.transpose(-1, -2)) / 8.0
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    lse_ref = torch.logsumexp(s, -1).reshape(-1)
+    assert float((lse.cpu() - lse_ref).abs().max()) < 2e-2
+    # backward
+    dout = torch.randn(N * L, d, generator=g).to(dtype)
+    do = dout.float().reshape(N, L, H, 64).permute(0, 2, 1, 3)
+    dq, dk, dv = O.attention_bwd(do, q, k, v, p)
+    dqkv_ref = torch.cat([t.permute(0, 2, 1, 3).reshape(N * L, d) for t in (dq, dk, dv)], dim=-1)
+    dqkv = E.op_attention_bwd(qkv.cuda(), out, dout.cuda(), lse, N, L, H, causal)
+    for i, nm in enumerate("qkv"):
+        e = relerr(dqkv[:, i * d:(i + 1) * d], dqkv_ref[:, i * d:(i + 1) * d])
+        assert e < TOL[dtype] * 3, f"d{nm}: {e}"
+
+
+def test_attention_is_not_transposed():
+    """Asymmetric probe: one query attends to one spiked key; V rows are distinct ramps."""
+    E = _eng()
+    N, L, H = 1, 40, 1
+    qkv = torch.zeros(L, 192)
+    qkv[:, 128:] = torch.arange(L).float().view(L, 1) * 0.01 + torch.arange(64).float().view(1, 64) * 1e-3
+    qkv[7, 0] = 8.0       # q_7
+    qkv[23, 64] = 8.0     # k_23  -> score(7,23) = 64/8 = 8
+    out, _ = E.op_attention_fwd(qkv.half().cuda(), N, L, H, False)
+    _, _, _, o, _ = _attn_ref(qkv.half(), N, L, H, False)
+    assert relerr(out, o.reshape(L, 64)) < 3e-3
