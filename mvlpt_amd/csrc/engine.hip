@@ -62,7 +62,7 @@ struct TowerState {
   std::vector<void*> qkv, attn, u;       // per layer (all equal when !saved)
   std::vector<float*> lse;
   void *h16 = nullptr, *a16 = nullptr;
-  float* dx32 = nullptr; void *dx16 = nullptr, *du16 = nullptr, *dh16 = nullptr, *dO16 = nullptr, *dqkv16 = nullptr;
+  float* dx32 = nullptr; void *dx16 = nullptr, *du16 = nullptr, *dO16 = nullptr, *dqkv16 = nullptr; float* dh32 = nullptr;
   float* delta = nullptr; float* scale_dev = nullptr;
   std::vector<char> skip;                // layer skipped (reference deep-prompt quirk, Appendix A.3)
 };
@@ -79,17 +79,17 @@ struct Engine {
   TowerW vis, txt;
   // vision extras
   void* conv_w = nullptr; int Kp = 0; float* cls_emb = nullptr; float* vpos = nullptr; LNp ln_pre, ln_post;
-  void *vproj = nullptr, *vproj_t = nullptr;   // [dv,e] and [e,dv] 16-bit
+  float *vproj = nullptr, *vproj_t = nullptr;  // [dv,e] and [e,dv] fp32 (the projections next to the logits stay fp32)
   // text extras
-  float* tpos = nullptr; LNp ln_final; void *tproj = nullptr, *tproj_t = nullptr;
+  float* tpos = nullptr; LNp ln_final; float *tproj = nullptr, *tproj_t = nullptr;
   std::vector<void*> owned;               // every weight allocation (freed in destroy)
   DevBuf vis_ws, txt_ws, head_ws, ce_ws, tmp;
   TowerState vs, ts;
   // vision fwd extras (carved from vis_ws)
-  int vB = 0, v_nvpt = 0, v_ndeep = 0; void* cls16 = nullptr; void* dfeat16_v = nullptr; void* dcls16 = nullptr;
+  int vB = 0, v_nvpt = 0, v_ndeep = 0; float* cls32 = nullptr; float* dcls32 = nullptr;
   // text fwd extras
   int tC = 0, tL = 0, t_nctx = 0, t_per_class = 0; int32_t* eot_rows = nullptr; int32_t* ctx_pos = nullptr;
-  void* eot16 = nullptr; void* dfeat16_t = nullptr; void* deot16 = nullptr;
+  float* eot32 = nullptr; float* deot32 = nullptr;
   // head state
   int hB = 0, hC = 0; float h_scale = 0.f; const int32_t *h_lo = nullptr, *h_hi = nullptr;
   float *imn = nullptr, *txn = nullptr, *inorm = nullptr, *tnorm = nullptr;
@@ -136,10 +136,10 @@ hipError_t ln_fwd(Engine* E, int out_dt, const float* x, const int32_t* idx, int
   ProfScope ps(E, s, PC_LN_FWD, 8.0 * rows * d, (double)rows * d * (4.0 + (out_dt == DT_F32 ? 4.0 : 2.0)));
   return launch_ln_fwd(out_dt, a, s);
 }
-hipError_t ln_bwd(Engine* E, const void* dy, const float* x, const int32_t* idx, int row_mul, const LNp& p, const float* resid,
-                  float* out32, void* out16, int rows, int d, hipStream_t s, int dtype = -1) {
-  LnBwdArgs a{dy, x, idx, row_mul, p.g, resid, out32, out16, rows, d};
-  ProfScope ps(E, s, PC_LN_BWD, 14.0 * rows * d, (double)rows * d * (2.0 + 4.0 + (resid ? 4.0 : 0.0) + 4.0 + (out16 ? 2.0 : 0.0)));
+hipError_t ln_bwd(Engine* E, const void* dy, int dy_dtype, const float* x, const int32_t* idx, int row_mul, const LNp& p,
+                  const float* resid, float* out32, void* out16, int rows, int d, hipStream_t s, int dtype = -1) {
+  LnBwdArgs a{dy, dy_dtype, x, idx, row_mul, p.g, resid, out32, out16, rows, d};
+  ProfScope ps(E, s, PC_LN_BWD, 14.0 * rows * d, (double)rows * d * ((dy_dtype == DT_F32 ? 4.0 : 2.0) + 4.0 + (resid ? 4.0 : 0.0) + 4.0 + (out16 ? 2.0 : 0.0)));
   return launch_ln_bwd(dtype >= 0 ? dtype : E->dt, a, s);
 }
 
@@ -155,7 +155,7 @@ size_t tower_bytes(const TowerW& W, int N, int L, bool save) {
   b += (save ? nl : 1) * align256(T * 4 * d * 2);                    // u
   b += align256(T * 4 * d * 2);                                      // a16
   if (save) {
-    b += align256(T * d * 4) + 3 * align256(T * d * 2) + align256(T * d * 2) + align256(T * 4 * d * 2) + align256(T * 3 * d * 2);
+    b += 2 * align256(T * d * 4) + 3 * align256(T * d * 2) + align256(T * 4 * d * 2) + align256(T * 3 * d * 2);
     b += align256((size_t)N * H * L * 4) + 256;
   }
   return b + 4096;
@@ -178,7 +178,7 @@ void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool s
   st.a16 = bp.take_bytes(T * 4 * d * 2);
   if (save) {
     st.dx32 = bp.take<float>(T * d);
-    st.dx16 = bp.take_bytes(T * d * 2); st.dh16 = bp.take_bytes(T * d * 2); st.dO16 = bp.take_bytes(T * d * 2);
+    st.dx16 = bp.take_bytes(T * d * 2); st.dh32 = bp.take<float>(T * d); st.dO16 = bp.take_bytes(T * d * 2);
     st.du16 = bp.take_bytes(T * 4 * d * 2); st.dqkv16 = bp.take_bytes(T * 3 * d * 2);
     st.delta = bp.take<float>((size_t)N * H * L);
     st.scale_dev = bp.take<float>(2);
@@ -211,8 +211,9 @@ int block_bwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) 
   const Block& B = W.blocks[l];
   const int T = st.N * st.L, d = st.d;
   HIPCHK(E, gemm(E, EPI_GELUBWD, st.dx16, B.pr.wt, T, 4 * d, d, nullptr, st.u[l], nullptr, st.du16, nullptr, s));
-  HIPCHK(E, gemm(E, EPI_STORE16, st.du16, B.fc.wt, T, d, 4 * d, nullptr, nullptr, nullptr, st.dh16, nullptr, s));
-  HIPCHK(E, ln_bwd(E, st.dh16, st.x[2 * l + 1], nullptr, 1, B.ln2, st.dx32, st.dx32, st.dx16, T, d, s));
+  // the dX GEMMs that feed a LayerNorm backward store fp32 (one 16-bit rounding less per half layer)
+  HIPCHK(E, gemm(E, EPI_STORE32, st.du16, B.fc.wt, T, d, 4 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s));
+  HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l + 1], nullptr, 1, B.ln2, st.dx32, st.dx32, st.dx16, T, d, s));
   HIPCHK(E, gemm(E, EPI_STORE16, st.dx16, B.o.wt, T, d, d, nullptr, nullptr, nullptr, st.dO16, nullptr, s));
   {
     AttnBwdArgs a{st.qkv[l], st.attn[l], st.dO16, st.lse[l], st.delta, st.dqkv16, st.N, st.L, st.H, st.causal ? 1 : 0};
@@ -220,8 +221,8 @@ int block_bwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) 
     ProfScope ps(E, s, PC_ATTN_BWD, fl, (double)T * d * 2.0 * 8.0);
     HIPCHK(E, launch_attn_bwd(E->dt, a, s));
   }
-  HIPCHK(E, gemm(E, EPI_STORE16, st.dqkv16, B.qkv.wt, T, d, 3 * d, nullptr, nullptr, nullptr, st.dh16, nullptr, s));
-  HIPCHK(E, ln_bwd(E, st.dh16, st.x[2 * l], nullptr, 1, B.ln1, st.dx32, st.dx32, st.dx16, T, d, s));
+  HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, B.qkv.wt, T, d, 3 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s));
+  HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, B.ln1, st.dx32, st.dx32, st.dx16, T, d, s));
   return 0;
 }
 
@@ -390,17 +391,24 @@ int mvlpt_load_frozen(void* h, const char* name, const void* dev_ptr, int dtype,
   } else if (nm == "visual.ln_post.bias") { if (!is1(dv)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->ln_post.b, s);
   } else if (nm == "visual.proj") {
     if (!is2(dv, e)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm);
-    Linear L;  // proj is [in=dv, out=e]: forward Bt = proj^T [e,dv]; dX Bt = proj [dv,e]
-    rc = pack_linear(E, p32, dv, e, &L, s);
-    E->vproj = L.w; E->vproj_t = L.wt;
+    // proj is [dv,e]: forward Bt = proj^T [e,dv]; dX Bt = proj [dv,e]; both kept in fp32
+    void *w = nullptr, *wt = nullptr;
+    HIPCHK(E, hipMalloc(&w, n * 4)); E->owned.push_back(w);
+    HIPCHK(E, hipMalloc(&wt, n * 4)); E->owned.push_back(wt);
+    HIPCHK(E, launch_pack_weight(DT_F32, p32, w, dv, e, e, s));
+    HIPCHK(E, launch_pack_weight_t(DT_F32, p32, wt, dv, e, s));
+    E->vproj = (float*)w; E->vproj_t = (float*)wt;
   } else if (nm == "positional_embedding") { if (!is2(A.context_length, dtw)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->tpos, s);
   } else if (nm == "ln_final.weight") { if (!is1(dtw)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->ln_final.g, s);
   } else if (nm == "ln_final.bias") { if (!is1(dtw)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm); rc = upload_f32(E, p32, n, &E->ln_final.b, s);
   } else if (nm == "text_projection") {
     if (!is2(dtw, e)) return fail(E, MVLPT_ERR_ARG, "shape mismatch: " + nm);
-    Linear L;
-    rc = pack_linear(E, p32, dtw, e, &L, s);
-    E->tproj = L.w; E->tproj_t = L.wt;
+    void *w = nullptr, *wt = nullptr;
+    HIPCHK(E, hipMalloc(&w, n * 4)); E->owned.push_back(w);
+    HIPCHK(E, hipMalloc(&wt, n * 4)); E->owned.push_back(wt);
+    HIPCHK(E, launch_pack_weight(DT_F32, p32, w, dtw, e, e, s));
+    HIPCHK(E, launch_pack_weight_t(DT_F32, p32, wt, dtw, e, s));
+    E->tproj = (float*)w; E->tproj_t = (float*)wt;
   } else {
     return fail(E, MVLPT_ERR_ARG, "unknown frozen tensor name: " + nm);
   }
@@ -433,15 +441,14 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   const bool save = save_for_bwd != 0;
   const size_t npatch = (size_t)B * G2;
   size_t need = tower_bytes(E->vis, B, Lv, save) + align256(npatch * E->Kp * 2) + align256(npatch * dv * 4) +
-                3 * align256((size_t)B * dv * 2) + align256((size_t)B * e * 2) + 4096;
+                2 * align256((size_t)B * dv * 4) + 4096;
   E->vs.valid = false;
   HIPCHK(E, E->vis_ws.reserve(need));
   Bump bp; bp.base = (char*)E->vis_ws.p; bp.cap = E->vis_ws.cap;
   void* patches = bp.take_bytes(npatch * E->Kp * 2);
   float* pe = bp.take<float>(npatch * dv);
-  E->cls16 = bp.take_bytes((size_t)B * dv * 2);
-  E->dcls16 = bp.take_bytes((size_t)B * dv * 2);
-  E->dfeat16_v = bp.take_bytes((size_t)B * e * 2);
+  E->cls32 = bp.take<float>((size_t)B * dv);
+  E->dcls32 = bp.take<float>((size_t)B * dv);
   carve_tower(bp, E->vis, E->vs, B, Lv, save, false);
   TowerState& st = E->vs;
   E->vB = B; E->v_nvpt = n_vpt; E->v_ndeep = n_deep;
@@ -468,8 +475,9 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
     if (int rc = block_fwd(E, E->vis, st, l, s)) return rc;
   }
   // ln_post on the CLS row, then @ proj   (trainers/mvlpt.py:88-91)
-  HIPCHK(E, ln_fwd(E, E->dt, st.x[2 * E->vis.layers], nullptr, Lv, E->ln_post, E->cls16, B, dv, s));
-  HIPCHK(E, gemm(E, EPI_STORE32, E->cls16, E->vproj_t, B, e, dv, nullptr, nullptr, nullptr, feat_out, nullptr, s));
+  HIPCHK(E, ln_fwd(E, DT_F32, st.x[2 * E->vis.layers], nullptr, Lv, E->ln_post, E->cls32, B, dv, s));
+  { ProfScope ps(E, s, PC_HEAD, 2.0 * B * e * dv, 4.0 * ((double)B * dv + (double)e * dv + (double)B * e));
+    HIPCHK(E, launch_sgemm_bt(E->cls32, E->vproj_t, feat_out, B, e, dv, nullptr, s)); }
   return 0;
 }
 
@@ -485,11 +493,10 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
   const size_t T = (size_t)B * Lv;
   { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 10.0);
     HIPCHK(E, launch_grad_scale(dfeat, (size_t)B * e, 64.0f, st.scale_dev, s));
-    HIPCHK(E, launch_cast_f32_to16(E->dt, dfeat, E->dfeat16_v, (size_t)B * e, st.scale_dev, s)); }
-  HIPCHK(E, gemm(E, EPI_STORE16, E->dfeat16_v, E->vproj, B, dv, e, nullptr, nullptr, nullptr, E->dcls16, nullptr, s));
+    HIPCHK(E, launch_sgemm_bt(dfeat, E->vproj, E->dcls32, B, dv, e, st.scale_dev, s)); }
   { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 4.0);
     HIPCHK(E, launch_zero(st.dx32, T * dv * 4, s)); }
-  HIPCHK(E, ln_bwd(E, E->dcls16, st.x[2 * st.layers], nullptr, Lv, E->ln_post, nullptr, st.dx32, nullptr, B, dv, s));
+  HIPCHK(E, ln_bwd(E, E->dcls32, DT_F32, st.x[2 * st.layers], nullptr, Lv, E->ln_post, nullptr, st.dx32, nullptr, B, dv, s));
   { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 6.0);
     HIPCHK(E, launch_cast_f32_to16(E->dt, st.dx32, st.dx16, T * dv, nullptr, s)); }
   for (int l = st.layers - 1; l >= 0; --l) {
@@ -523,14 +530,13 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
   hipStream_t s = (hipStream_t)stream;
   const int dtw = A.text_width, e = A.embed_dim;
   const bool save = save_for_bwd != 0;
-  size_t need = tower_bytes(E->txt, C, L, save) + 3 * align256((size_t)C * dtw * 2) + align256((size_t)C * e * 2) +
+  size_t need = tower_bytes(E->txt, C, L, save) + 2 * align256((size_t)C * dtw * 4) +
                 align256((size_t)C * 4) + align256((size_t)C * (n_ctx > 0 ? n_ctx : 1) * 4) + 4096;
   E->ts.valid = false;
   HIPCHK(E, E->txt_ws.reserve(need));
   Bump bp; bp.base = (char*)E->txt_ws.p; bp.cap = E->txt_ws.cap;
-  E->eot16 = bp.take_bytes((size_t)C * dtw * 2);
-  E->deot16 = bp.take_bytes((size_t)C * dtw * 2);
-  E->dfeat16_t = bp.take_bytes((size_t)C * e * 2);
+  E->eot32 = bp.take<float>((size_t)C * dtw);
+  E->deot32 = bp.take<float>((size_t)C * dtw);
   E->eot_rows = bp.take<int32_t>(C);
   E->ctx_pos = bp.take<int32_t>((size_t)C * (n_ctx > 0 ? n_ctx : 1));
   carve_tower(bp, E->txt, E->ts, C, L, save, true);
@@ -542,8 +548,9 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
     if (save && n_ctx > 0) HIPCHK(E, launch_build_ctx_pos(layout, E->ctx_pos, C, L, n_ctx, s)); }
   for (int l = 0; l < E->txt.layers; ++l)
     if (int rc = block_fwd(E, E->txt, st, l, s)) return rc;
-  HIPCHK(E, ln_fwd(E, E->dt, st.x[2 * E->txt.layers], E->eot_rows, 1, E->ln_final, E->eot16, C, dtw, s));
-  HIPCHK(E, gemm(E, EPI_STORE32, E->eot16, E->tproj_t, C, e, dtw, nullptr, nullptr, nullptr, feat_out, nullptr, s));
+  HIPCHK(E, ln_fwd(E, DT_F32, st.x[2 * E->txt.layers], E->eot_rows, 1, E->ln_final, E->eot32, C, dtw, s));
+  { ProfScope ps(E, s, PC_HEAD, 2.0 * C * e * dtw, 4.0 * ((double)C * dtw + (double)e * dtw + (double)C * e));
+    HIPCHK(E, launch_sgemm_bt(E->eot32, E->tproj_t, feat_out, C, e, dtw, nullptr, s)); }
   return 0;
 }
 
@@ -559,11 +566,10 @@ int mvlpt_text_bwd(void* h, const float* dfeat, float* dctx, mvlpt_stream_t stre
   const size_t T = (size_t)C * L;
   { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dtw * 10.0);
     HIPCHK(E, launch_grad_scale(dfeat, (size_t)C * e, 64.0f, st.scale_dev, s));
-    HIPCHK(E, launch_cast_f32_to16(E->dt, dfeat, E->dfeat16_t, (size_t)C * e, st.scale_dev, s)); }
-  HIPCHK(E, gemm(E, EPI_STORE16, E->dfeat16_t, E->tproj, C, dtw, e, nullptr, nullptr, nullptr, E->deot16, nullptr, s));
+    HIPCHK(E, launch_sgemm_bt(dfeat, E->tproj, E->deot32, C, dtw, e, st.scale_dev, s)); }
   { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dtw * 4.0);
     HIPCHK(E, launch_zero(st.dx32, T * dtw * 4, s)); }
-  HIPCHK(E, ln_bwd(E, E->deot16, st.x[2 * st.layers], E->eot_rows, 1, E->ln_final, nullptr, st.dx32, nullptr, C, dtw, s));
+  HIPCHK(E, ln_bwd(E, E->deot32, DT_F32, st.x[2 * st.layers], E->eot_rows, 1, E->ln_final, nullptr, st.dx32, nullptr, C, dtw, s));
   { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dtw * 6.0);
     HIPCHK(E, launch_cast_f32_to16(E->dt, st.dx32, st.dx16, T * dtw, nullptr, s)); }
   for (int l = st.layers - 1; l >= 0; --l)
@@ -642,7 +648,7 @@ int mvlpt_op_layernorm_fwd(int out_dtype, const float* x, const float* gamma, co
 }
 int mvlpt_op_layernorm_bwd(int dtype, const void* dy, const float* x, const float* gamma, const float* resid, float* out32,
                            void* out16, int rows, int d, mvlpt_stream_t stream) {
-  LnBwdArgs a{dy, x, nullptr, 1, gamma, resid, out32, out16, rows, d};
+  LnBwdArgs a{dy, dtype, x, nullptr, 1, gamma, resid, out32, out16, rows, d};
   OPCHK(launch_ln_bwd(dtype, a, (hipStream_t)stream));
   return 0;
 }

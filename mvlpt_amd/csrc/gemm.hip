@@ -184,4 +184,41 @@ hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s) {
   return hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------------------------------------- fp32 GEMM
+// One wave per 16x16 output tile, straight from global memory (the operands are a few hundred KB and
+// L2-resident): each lane loads 4 consecutive k of its row (16 B), 4 x v_mfma_f32_16x16x4_f32 per step.
+// A/B k-slot of lane l in MFMA j is  k0 + 4*(l>>4) + j  on both operands (any consistent map is exact).
+__global__ __launch_bounds__(256) void sgemm_bt_kernel(const float* __restrict__ A, const float* __restrict__ Bt,
+                                                       float* __restrict__ Cm, int M, int N, int K, const float* alpha_dev) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tilesN = (N + 15) / 16;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= ((M + 15) / 16) * tilesN) return;
+  const int m0 = (tile / tilesN) * 16, n0 = (tile % tilesN) * 16;
+  const int fr = lane & 15, fg = lane >> 4;
+  int ar = m0 + fr; ar = ar < M ? ar : M - 1;
+  int br = n0 + fr; br = br < N ? br : N - 1;
+  const float* ap = A + (size_t)ar * K + fg * 4;
+  const float* bp = Bt + (size_t)br * K + fg * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const f32x4 a4 = *(const f32x4*)(ap + k0);
+    const f32x4 b4 = *(const f32x4*)(bp + k0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b4[j], a4[j], acc, 0, 0, 0);
+  }
+  // swapped operands: lane holds C[m0 + fr][n0 + 4*fg + 0..3]
+  const int m = m0 + fr, n = n0 + fg * 4;
+  if (m < M && n < N) {
+    const float alpha = alpha_dev ? alpha_dev[0] : 1.0f;
+    *(f32x4*)(Cm + (size_t)m * N + n) = acc * alpha;
+  }
+}
+hipError_t launch_sgemm_bt(const float* A, const float* Bt, float* C, int M, int N, int K, const float* alpha_dev, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 16) || (N % 4)) return hipErrorInvalidValue;
+  const int tiles = ((M + 15) / 16) * ((N + 15) / 16);
+  hipLaunchKernelGGL(sgemm_bt_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, A, Bt, C, M, N, K, alpha_dev);
+  return hipGetLastError();
+}
+
 }  // namespace mvlpt

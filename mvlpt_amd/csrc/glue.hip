@@ -56,7 +56,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 hipError_t launch_pack_weight(int dtype, const float* w, void* out, int rows, int cols, int ld_out, hipStream_t s) {
   const size_t n = (size_t)rows * ld_out;
   const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  if (dtype == DT_F16) hipLaunchKernelGGL(pack_weight_kernel<f16>, dim3(grid), dim3(256), 0, s, w, (f16*)out, rows, cols, ld_out);
+  if (dtype == DT_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)out, rows, cols, ld_out);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(pack_weight_kernel<f16>, dim3(grid), dim3(256), 0, s, w, (f16*)out, rows, cols, ld_out);
   else if (dtype == DT_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(grid), dim3(256), 0, s, w, (bf16*)out, rows, cols, ld_out);
   else return hipErrorInvalidValue;
   return hipGetLastError();
@@ -80,7 +81,8 @@ __global__ void pack_weight_t_kernel(const float* __restrict__ w, T* __restrict_
 }
 hipError_t launch_pack_weight_t(int dtype, const float* w, void* out, int rows, int cols, hipStream_t s) {
   dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
-  if (dtype == DT_F16) hipLaunchKernelGGL(pack_weight_t_kernel<f16>, grid, block, 0, s, w, (f16*)out, rows, cols);
+  if (dtype == DT_F32) hipLaunchKernelGGL(pack_weight_t_kernel<float>, grid, block, 0, s, w, (float*)out, rows, cols);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(pack_weight_t_kernel<f16>, grid, block, 0, s, w, (f16*)out, rows, cols);
   else if (dtype == DT_BF16) hipLaunchKernelGGL(pack_weight_t_kernel<bf16>, grid, block, 0, s, w, (bf16*)out, rows, cols);
   else return hipErrorInvalidValue;
   return hipGetLastError();

@@ -25,6 +25,10 @@ struct GemmArgs {
 };
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s);
 
+// fp32 GEMM on the f32-input MFMA (exact f32 products, v_mfma_f32_16x16x4_f32) for the two tiny projections
+// next to the logits (CLS / EOT rows only): C[M,N] = alpha * A[M,K] * Bt[N,K]^T.  K % 16 == 0, N % 4 == 0.
+hipError_t launch_sgemm_bt(const float* A, const float* Bt, float* C, int M, int N, int K, const float* alpha_dev, hipStream_t s);
+
 // ---------------------------------------------------------------- LayerNorm (fp32 statistics)
 // Input row r is read at  x + in_row(r) * d  with in_row(r) = row_idx ? row_idx[r] : r * row_mul.
 struct LnFwdArgs {
@@ -36,7 +40,8 @@ struct LnFwdArgs {
 hipError_t launch_ln_fwd(int out_dtype, const LnFwdArgs& a, hipStream_t s);
 
 struct LnBwdArgs {
-  const void* dy;        // [rows,d] contiguous 16-bit
+  const void* dy;        // [rows,d] contiguous, 16-bit (dy_dtype = compute dtype) or fp32 (dy_dtype = DT_F32)
+  int dy_dtype;
   const float* x; const int32_t* row_idx; int row_mul;   // LN input rows (same mapping as forward)
   const float* gamma;
   const float* resid;    // fp32, same row mapping as x, or null:  out32 = resid + dx

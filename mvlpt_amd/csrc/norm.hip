@@ -72,14 +72,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
   }
 }
 
-template <typename T>
+template <typename TDY, typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
   const size_t in_row = a.row_idx ? (size_t)a.row_idx[row] : (size_t)row * a.row_mul;
   const float* x = a.x + in_row * a.d;
-  const T* dy = (const T*)a.dy + (size_t)row * a.d;
+  const TDY* dy = (const TDY*)a.dy + (size_t)row * a.d;
   f32x4 v[LN_MAXV], gg[LN_MAXV]; bool ok[LN_MAXV];
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
   for (int i = 0; i < LN_MAXV; ++i) if (ok[i]) {
     const int c = (i * 64 + lane) * 4;
     const f32x4 g = *(const f32x4*)(a.gamma + c);
-    const f32x4 d = load4<T>(dy + c);
+    const f32x4 d = load4<TDY>(dy + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       v[i][e] = (v[i][e] - mean) * rstd;   // xhat
@@ -132,9 +132,14 @@ hipError_t launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s) {
   if (a.rows <= 0) return hipSuccess;
   if (a.d % 4 != 0 || a.d > LN_MAXV * 256) return hipErrorInvalidValue;
   dim3 grid((a.rows + 3) / 4), block(256);
-  if (dtype == DT_F16) hipLaunchKernelGGL(ln_bwd_kernel<f16>, grid, block, 0, s, a);
-  else if (dtype == DT_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16>, grid, block, 0, s, a);
-  else return hipErrorInvalidValue;
+  const bool dy32 = a.dy_dtype == DT_F32;
+  if (dtype == DT_F16) {
+    if (dy32) hipLaunchKernelGGL((ln_bwd_kernel<float, f16>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((ln_bwd_kernel<f16, f16>), grid, block, 0, s, a);
+  } else if (dtype == DT_BF16) {
+    if (dy32) hipLaunchKernelGGL((ln_bwd_kernel<float, bf16>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((ln_bwd_kernel<bf16, bf16>), grid, block, 0, s, a);
+  } else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -1,0 +1,77 @@
+"""One process per GPU; RCCL (torch.distributed backend "nccl" on ROCm) over xGMI, gloo on CPU for tests.
+
+The prompted-CLIP step shards over images with NO data-path collective in the towers: every rank holds the
+frozen CLIP and its slice of the batch.  The single exchange per step is one all-reduce (sum) of ONE flat fp32
+buffer holding every prompt-learner gradient — 8 192 elements for CoOp-16, 73 728 for VPT-deep-8, 566 400 for
+UPT-4 (32 KB … 2.3 MB): latency-bound, so it is a single collective instead of one per parameter
+(SURVEY.md §8e).  It replaces nn.DataParallel's per-step replicate/scatter/gather (trainers/mvlpt.py:877-880).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def rank_info() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torchrun environment (1 process when absent)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init_process_group(backend: str | None = None) -> Tuple[int, int, int]:
+    rank, world, local = rank_info()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int) -> None:
+    """grad <- mean over ranks, through one flat buffer (each rank's loss is the mean over its own slice, all
+    slices have the same size, so the mean of rank gradients is the gradient of the global-batch mean loss)."""
+    grads: List[torch.Tensor] = [p.grad for p in params if p.requires_grad and p.grad is not None]
+    if world_size <= 1 or not grads:
+        return
+    flat = torch.cat([g.reshape(-1).float() for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.mul_(1.0 / world_size)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
+    if not dist.is_initialized():
+        return
+    tensors = [p.data for p in module.parameters()]
+    if not tensors:
+        return
+    flat = torch.cat([t.reshape(-1).float() for t in tensors])
+    dist.broadcast(flat, src=src)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+
+
+def barrier() -> None:
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def all_reduce_max(value: float, device) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

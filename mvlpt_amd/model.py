@@ -1,0 +1,389 @@
+"""Host-side mirror of the reference's prompted-CLIP model API (trainers/mvlpt.py:138-583), MI355X-native.
+
+Same class names, constructor arguments, attribute names and — most importantly — the same
+``prompt_learner.state_dict()`` keys (``ctx``, ``vpt_embeddings``, ``vpt_embeddings_deep``, ``token_prefix``,
+``token_suffix``, ``mvlpt_proj.resblocks.0.*``, ``mvlpt_proj_ctx_{coop,vpt}_{pre,post}.*``), so checkpoints
+interoperate and ``self.model(image, task=…)`` / ``self.model.prompt_learner`` work under the trainer exactly
+as in the reference.  The towers do NOT run on PyTorch ops: `CustomCLIP.forward` is one
+``torch.autograd.Function`` whose forward/backward call libmvlpt_hip.so (hand-written gfx950 kernels).  Only the
+tiny UPT projection (forward_mvlpt_proj, ≤52 tokens × width 128, trainable weights) stays on torch autograd.
+
+Deviations (documented in DESIGN.md): prompt parameters are kept in fp32 even when PREC == "fp16" (fp32 master
+copies; the reference keeps fp16 parameters and has no loss scaling); CoCoOp (COCOOP.N_CTX != 0) is out of scope.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from functools import reduce
+from operator import mul
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .engine import Engine
+from .weights import ClipArch, _randn, arch_from_state_dict
+
+SOT_TOKEN, EOT_TOKEN = 49406, 49407     # clip/simple_tokenizer.py: <|startoftext|>, <|endoftext|>
+X_TOKEN = 343                            # "X" placeholder word (trainers/mvlpt.py:227), from tests/golden/tokens.npz
+
+
+# ------------------------------------------------------------------------------------------------ tokenisation
+class SyntheticTokenizer:
+    """Offline stand-in for clip.simple_tokenizer (the BPE vocabulary cannot be shipped to the GPU box in round 1;
+    SURVEY §8f row 4).  One pseudo-token per whitespace-separated word (stable hash), which reproduces the
+    *structure* the hot path depends on: [SOT, prefix words…, name words…, '.', EOT, 0…] and name_lens."""
+
+    def encode(self, text: str) -> List[int]:
+        out = []
+        for w in text.replace(".", " .").split():
+            if w == "X":
+                out.append(X_TOKEN)
+            elif w == ".":
+                out.append(269)
+            else:
+                h = 0
+                for ch in w.lower():
+                    h = (h * 131 + ord(ch)) % 40000
+                out.append(1000 + h)
+        return out
+
+    def tokenize(self, texts, context_length: int = 77) -> torch.Tensor:
+        """Same contract as clip.tokenize (clip/clip.py:187-223)."""
+        if isinstance(texts, str):
+            texts = [texts]
+        res = torch.zeros(len(texts), context_length, dtype=torch.long)
+        for i, t in enumerate(texts):
+            ids = [SOT_TOKEN] + self.encode(t) + [EOT_TOKEN]
+            if len(ids) > context_length:
+                raise RuntimeError(f"Input {t} is too long for context length {context_length}")
+            res[i, :len(ids)] = torch.tensor(ids)
+        return res
+
+
+class PretokenizedPrompts:
+    """Token ids produced elsewhere (e.g. by the reference tokenizer, stored in a fixture)."""
+
+    def __init__(self, tokenized_prompts: torch.Tensor, name_lens: Sequence[int]):
+        self.tokenized_prompts = tokenized_prompts.long()
+        self.name_lens = [int(x) for x in name_lens]
+
+
+def build_prompt_layout(name_lens: Sequence[int], n_ctx: int, L: int, position: str) -> torch.Tensor:
+    """Source-row table [C, L] (int32) equivalent to the torch.cat's of forward_coop (trainers/mvlpt.py:439-515):
+    0 = token_prefix, e > 0 = token_suffix[e-1], e < 0 = ctx[-e-1]."""
+    rows = []
+    for nl in name_lens:
+        ctx = [-(j + 1) for j in range(n_ctx)]
+        fixed = list(range(L - n_ctx))
+        if n_ctx == 0:
+            row = fixed
+        elif position == "end":
+            row = fixed[:1] + ctx + fixed[1:]
+        elif position == "middle":
+            half = n_ctx // 2
+            row = fixed[:1] + ctx[:half] + fixed[1:1 + nl] + ctx[half:] + fixed[1 + nl:]
+        elif position == "front":
+            row = fixed[:1] + fixed[1:1 + nl] + ctx + fixed[1 + nl:]
+        else:
+            raise ValueError(position)
+        if len(row) != L:
+            raise ValueError("layout length mismatch")
+        rows.append(row)
+    return torch.tensor(rows, dtype=torch.int32)
+
+
+# ------------------------------------------------------------------------------------------------ frozen CLIP
+class FrozenCLIP:
+    """What the reference passes around as ``clip_model``: here the frozen weights live packed inside the
+    HIP engine; this object only carries what the prompt learner needs at construction time."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], compute_dtype: str = "fp16", device=None,
+                 tokenizer=None, arch: Optional[ClipArch] = None, token_seed: int = 0):
+        self.arch = arch or arch_from_state_dict(state_dict)
+        self.engine = Engine.from_state_dict(state_dict, compute_dtype, device, self.arch)
+        self.device = self.engine.device
+        self.context_length = self.arch.context_length
+        self.logit_scale = state_dict["logit_scale"].detach().float().to(self.device)     # frozen, clip/model.py:291
+        self.tokenizer = tokenizer or SyntheticTokenizer()
+        self._token_embedding = state_dict.get("token_embedding.weight")
+        self._token_seed = token_seed
+        self.dtype = torch.float32   # dtype of the prompt parameters (see module docstring)
+
+    def token_embedding(self, ids: torch.Tensor) -> torch.Tensor:
+        """clip_model.token_embedding(tokenized_prompts) (trainers/mvlpt.py:306-307); init-time only, CPU."""
+        if self._token_embedding is None:
+            self._token_embedding = _randn("token_embedding.weight", self._token_seed,
+                                           (self.arch.vocab_size, self.arch.transformer_width), 0.02)
+        return self._token_embedding.float().cpu()[ids.cpu()]
+
+
+# ------------------------------------------------------------------------------------------------ UPT projection
+class _ProjAttention(nn.Module):
+    """Parameter container with nn.MultiheadAttention's names (in_proj_weight, in_proj_bias, out_proj.*)."""
+
+    def __init__(self, d: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = nn.Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _ProjBlock(nn.Module):
+    """clip.model.ResidualAttentionBlock(width, heads=1) as the reference USES it in forward_mvlpt_proj
+    (trainers/mvlpt.py:403-407): a batch-first [1,T,D] tensor goes into a seq-first block, so attention sees
+    sequence length 1 and the softmax over the single key is 1:
+        x + out_proj(v_proj(ln_1(x)));  then  + c_proj(QuickGELU(c_fc(ln_2(.))))."""
+
+    def __init__(self, d: int):
+        super().__init__()
+        self.attn = _ProjAttention(d)
+        self.ln_1 = nn.LayerNorm(d)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(d, 4 * d)), ("gelu", nn.Identity()),
+                                              ("c_proj", nn.Linear(4 * d, d))]))
+        self.ln_2 = nn.LayerNorm(d)
+
+    def forward(self, x):
+        d = x.shape[-1]
+        wv, bv = self.attn.in_proj_weight[2 * d:], self.attn.in_proj_bias[2 * d:]
+        x = x + self.attn.out_proj(nn.functional.linear(self.ln_1(x), wv, bv))
+        u = self.mlp.c_fc(self.ln_2(x))
+        return x + self.mlp.c_proj(u * torch.sigmoid(1.702 * u))
+
+
+class _ProjTransformer(nn.Module):
+    def __init__(self, width: int):
+        super().__init__()
+        self.width, self.layers = width, 1
+        self.resblocks = nn.Sequential(_ProjBlock(width))
+
+    def forward(self, x):
+        return self.resblocks(x)
+
+
+# ------------------------------------------------------------------------------------------------ prompt learner
+class MultitaskVLPromptLearner(nn.Module):
+    """trainers/mvlpt.py:138-515.  ``clip_model`` is a :class:`FrozenCLIP`; ``classnames`` a list of str, or a
+    :class:`PretokenizedPrompts` (then ``classnames`` only gives n_cls)."""
+
+    def __init__(self, cfg, classnames, clip_model: FrozenCLIP, pretokenized: Optional[PretokenizedPrompts] = None):
+        super().__init__()
+        n_cls = len(classnames)
+        T = cfg.TRAINER.MVLPT
+        coop_n_ctx, cocoop_n_ctx, vpt_n_ctx = T.COOP.N_CTX, T.COCOOP.N_CTX, T.VPT.N_CTX
+        if cocoop_n_ctx != 0:
+            raise NotImplementedError("CoCoOp (COCOOP.N_CTX != 0) is outside the MI355X hot path (SURVEY §2.1 #5)")
+        arch = clip_model.arch
+        dtype = clip_model.dtype
+        coop_ctx_dim, vpt_ctx_dim = arch.transformer_width, arch.vision_width
+        clip_imsize, cfg_imsize = arch.image_resolution, cfg.INPUT.SIZE[0]
+        assert cfg_imsize == clip_imsize, f"cfg_imsize ({cfg_imsize}) must equal to clip_imsize ({clip_imsize})"
+
+        self.vpt_dropout = nn.Dropout(T.VPT.DROPOUT)
+        if T.VPT.DROPOUT != 0.0:
+            raise NotImplementedError("VPT.DROPOUT != 0 is not supported by the HIP path (default 0.0, train.py:139)")
+        self.vpt_deep = T.VPT.DEEP
+        self.vpt_embeddings = None
+        self.vpt_embeddings_deep = None
+        prompt_prefix = ""
+        if vpt_n_ctx != 0:
+            if T.VPT.PROJECT > -1:
+                raise NotImplementedError("VPT.PROJECT > -1 is not supported (default -1 = Identity, train.py:140)")
+            self.vpt_proj = nn.Identity()
+            if T.VPT.CTX_INIT:
+                raise ValueError("CTX initiation scheme is not supported")            # :180-182
+            ps = arch.vision_patch_size
+            val = math.sqrt(6. / float(3 * reduce(mul, (ps, ps), 1) + vpt_ctx_dim))     # :186
+            self.vpt_embeddings = nn.Parameter(torch.zeros(1, vpt_n_ctx, vpt_ctx_dim, dtype=dtype))
+            nn.init.uniform_(self.vpt_embeddings.data, -val, val)
+            if self.vpt_deep:
+                self.vision_layers = arch.vision_layers
+                self.vpt_embeddings_deep = nn.Parameter(torch.zeros(arch.vision_layers - 1, vpt_n_ctx, vpt_ctx_dim, dtype=dtype))
+                nn.init.uniform_(self.vpt_embeddings_deep.data, -val, val)
+            prompt_prefix = "a photo of a "                                             # :201
+
+        self.ctx = None
+        if coop_n_ctx != 0:
+            if T.COOP.CTX_INIT:
+                init = T.COOP.CTX_INIT.replace("_", " ")
+                coop_n_ctx = len(init.split(" "))
+                ids = clip_model.tokenizer.tokenize(init)
+                ctx_vectors = clip_model.token_embedding(ids)[0, 1:1 + coop_n_ctx, :].to(dtype)   # :208-216
+                prompt_prefix = init
+            else:
+                shape = (n_cls, coop_n_ctx, coop_ctx_dim) if T.COOP.CSC else (coop_n_ctx, coop_ctx_dim)
+                ctx_vectors = torch.empty(*shape, dtype=dtype)
+                nn.init.normal_(ctx_vectors, std=0.02)                                  # :220-226
+                prompt_prefix = " ".join(["X"] * coop_n_ctx)
+            self.ctx = nn.Parameter(ctx_vectors)
+
+        self.mvlpt_proj = nn.Identity()
+        if vpt_n_ctx != 0 and coop_n_ctx != 0:
+            self.mvlpt_proj_ctx_dim = T.PROJECT_DIM
+            if T.PROJECT_METHOD == "identity":
+                self.mvlpt_proj = nn.Identity()
+            else:
+                self.mvlpt_proj_ctx_vpt_pre, self.mvlpt_proj_ctx_vpt_post = nn.Identity(), nn.Identity()
+                self.mvlpt_proj_ctx_coop_pre, self.mvlpt_proj_ctx_coop_post = nn.Identity(), nn.Identity()
+                D = self.mvlpt_proj_ctx_dim
+                if coop_ctx_dim != D:
+                    self.mvlpt_proj_ctx_coop_pre = nn.Linear(coop_ctx_dim, D, dtype=dtype)
+                    self.mvlpt_proj_ctx_coop_post = nn.Linear(D, coop_ctx_dim, dtype=dtype)
+                if vpt_ctx_dim != D:
+                    self.mvlpt_proj_ctx_vpt_pre = nn.Linear(vpt_ctx_dim, D, dtype=dtype)
+                    self.mvlpt_proj_ctx_vpt_post = nn.Linear(D, vpt_ctx_dim, dtype=dtype)
+                if T.PROJECT_METHOD == "transformer":
+                    self.mvlpt_proj = _ProjTransformer(D)
+                else:
+                    # 'mlp' crashes in the reference too (nn.GeLU, trainers/mvlpt.py:253)
+                    raise AttributeError("module 'torch.nn' has no attribute 'GeLU'")
+        self.cocoop_ctx = None
+
+        # ---- tokenisation + frozen token embeddings (init time, CPU) : trainers/mvlpt.py:292-316 ----
+        if pretokenized is not None:
+            tokenized_prompts, name_lens = pretokenized.tokenized_prompts, pretokenized.name_lens
+        else:
+            tok = clip_model.tokenizer
+            names = [n.replace("_", " ") for n in classnames]
+            name_lens = [len(tok.encode(n)) for n in names]
+            prompts = [prompt_prefix + " " + n + "." for n in names]
+            if cfg.TRAINER.CUT_CONTEXTLEN:
+                max_length = min(clip_model.context_length, max(len(tok.encode(p)) + 2 for p in prompts))
+            else:
+                max_length = clip_model.context_length
+            tokenized_prompts = torch.cat([tok.tokenize(p, context_length=max_length) for p in prompts])
+        with torch.no_grad():
+            embedding = clip_model.token_embedding(tokenized_prompts).to(dtype)
+        self.register_buffer("token_prefix", embedding[:, :1, :].contiguous())                       # SOS
+        self.register_buffer("token_suffix", embedding[:, 1 + coop_n_ctx:, :].contiguous())         # CLS, EOS
+
+        self.n_cls, self.vpt_n_ctx, self.coop_n_ctx, self.cocoop_n_ctx = n_cls, vpt_n_ctx, coop_n_ctx, 0
+        self.tokenized_prompts = tokenized_prompts
+        self.name_lens = list(name_lens)
+        self.class_token_position = T.COOP.CLASS_TOKEN_POSITION
+        L = tokenized_prompts.shape[1]
+        # integer tables consumed by the HIP text tower (bit-exact indexing)
+        self.register_buffer("layout", build_prompt_layout(self.name_lens, coop_n_ctx, L, self.class_token_position),
+                             persistent=False)
+        self.register_buffer("eot", tokenized_prompts.argmax(dim=-1).to(torch.int32), persistent=False)   # :128
+
+    # trainers/mvlpt.py:376-414
+    def forward_mvlpt_proj(self, dtype=torch.float):
+        if self.coop_n_ctx == 0 or isinstance(self.mvlpt_proj, nn.Identity) or self.vpt_n_ctx == 0:
+            return self.ctx, self.vpt_embeddings, self.vpt_embeddings_deep
+        vpt_emb = self.vpt_embeddings
+        if self.vpt_deep:
+            vpt_emb = torch.cat([vpt_emb, self.vpt_embeddings_deep], dim=0)
+        vpt_ctx_dim = vpt_emb.shape[-1]
+        vpt_emb = vpt_emb.reshape(1, -1, vpt_ctx_dim)
+        coop_emb = self.ctx
+        coop_ctx_dim = self.ctx.shape[-1]
+        if coop_emb.dim() == 2:
+            coop_emb = coop_emb.unsqueeze(0)
+        coop_emb = coop_emb.reshape(1, -1, coop_ctx_dim)
+        n = coop_emb.shape[1]
+        coop_emb = self.mvlpt_proj_ctx_coop_pre(coop_emb)
+        vpt_emb = self.mvlpt_proj_ctx_vpt_pre(vpt_emb)
+        e = self.mvlpt_proj(torch.cat([coop_emb, vpt_emb], dim=1).float()).type(dtype)
+        coop_emb, vpt_emb = e[:, :n, :], e[:, n:, :]
+        coop_emb = self.mvlpt_proj_ctx_coop_post(coop_emb).reshape(-1, self.coop_n_ctx, coop_ctx_dim).squeeze(0)
+        vpt_emb = self.mvlpt_proj_ctx_vpt_post(vpt_emb).reshape(-1, self.vpt_n_ctx, vpt_ctx_dim)
+        vpt_emb_deep = None if vpt_emb.shape[0] == 1 else vpt_emb[1:, :, :]
+        return coop_emb, vpt_emb[0, :, :].unsqueeze(0), vpt_emb_deep
+
+
+# ------------------------------------------------------------------------------------------------ autograd bridge
+class _PromptedClipFn(torch.autograd.Function):
+    """CustomCLIP.forward as ONE autograd node: forward and backward are libmvlpt_hip.so calls."""
+
+    @staticmethod
+    def forward(fctx, model: "CustomCLIP", image, task_lo, task_hi, coop_emb, vpt_emb, vpt_deep_emb):
+        eng = model.engine
+        pl = model.prompt_learner
+        # (grad mode is off inside Function.forward: ask autograd which inputs need a gradient)
+        need_txt = bool(fctx.needs_input_grad[4])
+        need_img = bool(fctx.needs_input_grad[5] or fctx.needs_input_grad[6])
+        img = eng.image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
+        if coop_emb is None and model._const_text_features is not None:
+            txt = model._const_text_features
+        else:
+            txt = eng.text_fwd(pl.token_prefix, pl.token_suffix, coop_emb, pl.layout, pl.eot, save_for_bwd=need_txt)
+            if coop_emb is None:
+                model._const_text_features = txt     # no text context: features are constants
+        logits = eng.logits_fwd(img, txt, model.logit_scale_exp, task_lo, task_hi)
+        fctx.model, fctx.need_img, fctx.need_txt = model, need_img, need_txt
+        fctx.has_deep = vpt_deep_emb is not None
+        fctx.vpt_shape = None if vpt_emb is None else vpt_emb.shape
+        return logits
+
+    @staticmethod
+    def backward(fctx, dlogits):
+        eng = fctx.model.engine
+        dimg, dtxt = eng.logits_bwd(dlogits.contiguous(), fctx.need_img, fctx.need_txt)
+        dctx = dvpt = ddeep = None
+        if fctx.need_txt:
+            dctx = eng.text_bwd(dtxt)
+        if fctx.need_img:
+            dvpt, ddeep = eng.image_bwd(dimg)
+            dvpt = dvpt.view(fctx.vpt_shape)
+        return None, None, None, None, dctx, dvpt, ddeep
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy (mean) with the gradient produced by the same fused HIP kernel."""
+
+    @staticmethod
+    def forward(fctx, model, logits, label):
+        loss, dl, nc = model.engine.cross_entropy(logits, label, need_grad=bool(fctx.needs_input_grad[1]))
+        if dl is not None:
+            fctx.save_for_backward(dl)
+        model.last_ncorrect = nc
+        return loss.squeeze(0)
+
+    @staticmethod
+    def backward(fctx, g):
+        (dl,) = fctx.saved_tensors
+        return None, dl * g, None
+
+
+class CustomCLIP(nn.Module):
+    """trainers/mvlpt.py:517-583."""
+
+    def __init__(self, cfg, classnames, clip_model: FrozenCLIP, dm=None, pretokenized: Optional[PretokenizedPrompts] = None):
+        super().__init__()
+        self.prompt_learner = MultitaskVLPromptLearner(cfg, classnames, clip_model, pretokenized)
+        self.tokenized_prompts = self.prompt_learner.tokenized_prompts
+        self.clip_model = clip_model
+        self.engine = clip_model.engine
+        self.logit_scale = clip_model.logit_scale
+        self.logit_scale_exp = float(clip_model.logit_scale.exp())
+        self.dtype = clip_model.dtype
+        self._const_text_features = None
+        self.last_ncorrect = None
+        self.multi_task_label_pertask = cfg.DATASET.MULTITASK_LABEL_PERTASK
+        if self.multi_task_label_pertask:
+            # indexed by task id; sized num_classes as in the reference (:529-537)
+            start = torch.arange(dm._num_classes)
+            end = torch.arange(dm._num_classes)
+            s = 0
+            for i, task in enumerate(dm._task_names):
+                start[i] = s
+                s += len(dm._labelmap[task])
+                end[i] = s
+            self.class_index_pertask_start, self.class_index_pertask_end = start, end
+
+    def forward(self, image, task=None):
+        coop_emb, vpt_emb, vpt_emb_deep = self.prompt_learner.forward_mvlpt_proj(self.dtype)
+        lo = hi = None
+        if self.multi_task_label_pertask:
+            t = task.cpu().long() if torch.is_tensor(task) else torch.as_tensor(task).long()
+            lo = self.class_index_pertask_start[t].to(torch.int32).to(image.device)
+            hi = self.class_index_pertask_end[t].to(torch.int32).to(image.device)
+        return _PromptedClipFn.apply(self, image, lo, hi, coop_emb, vpt_emb, vpt_emb_deep)
+
+    def cross_entropy(self, logits, label):
+        """HIP replacement for ``F.cross_entropy(output, label)`` (trainers/mvlpt.py:931)."""
+        return _CrossEntropyFn.apply(self, logits, label)

@@ -1,0 +1,315 @@
+"""Train-step driver with the reference's trainer surface (trainers/mvlpt.py:827-1125), MI355X-native.
+
+`MVLPT` keeps the method names / signatures the reference overrides on Dassl's ``TrainerX``
+(check_cfg, build_model, build_data_loader, forward_backward, parse_batch_train/test, model_inference,
+load_model) and the attributes it uses (self.model, self.optim, self.sched, self.device, batch_idx, …).
+Dassl itself is third-party, not vendored by the reference and unavailable offline, so `TrainerX` below is a
+minimal stand-in of the parts the hot path touches — epochs, SGD + cosine LR with
+constant warm-up, model registry, checkpoints in Dassl's dict format.
+
+Multi-GPU: one process per GPU (torch.distributed, RCCL); every rank holds the frozen CLIP and a slice of the
+batch; the only exchange per step is ONE all-reduce of the flat prompt-gradient buffer (mvlpt_amd/distributed.py)
+— this replaces nn.DataParallel (trainers/mvlpt.py:877-880), which re-broadcasts the frozen weights every step.
+"""
+from __future__ import annotations
+
+import math
+import os
+import os.path as osp
+import time
+from collections import OrderedDict
+from typing import Dict, Iterable, Optional
+
+import torch
+
+from . import distributed as dist_utils
+from .config import CfgNode
+from .model import CustomCLIP, FrozenCLIP
+from .weights import ARCHS, make_state_dict
+
+
+# ------------------------------------------------------------------------------------------------ Dassl stand-ins
+def build_optimizer(model: torch.nn.Module, optim_cfg) -> torch.optim.Optimizer:
+    """Dassl build_optimizer("sgd") defaults: over model.parameters()."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    name = optim_cfg.NAME.lower()
+    if name == "sgd":
+        return torch.optim.SGD(params, lr=optim_cfg.LR, momentum=optim_cfg.MOMENTUM, weight_decay=optim_cfg.WEIGHT_DECAY,
+                               dampening=optim_cfg.SGD_DAMPNING, nesterov=optim_cfg.SGD_NESTEROV)
+    if name == "adam":
+        return torch.optim.Adam(params, lr=optim_cfg.LR, weight_decay=optim_cfg.WEIGHT_DECAY)
+    raise ValueError(f"unsupported optimizer {optim_cfg.NAME}")
+
+
+class _ConstantWarmupCosine:
+    """CosineAnnealingLR(T_max = MAX_EPOCH) behind a constant warm-up (WARMUP_EPOCH at WARMUP_CONS_LR);
+    stepped once per epoch (trainers/mvlpt.py:948-949)."""
+
+    def __init__(self, optim, optim_cfg):
+        self.optim, self.cfg = optim, optim_cfg
+        self.base_lrs = [g["lr"] for g in optim.param_groups]
+        self.last_epoch = 0
+        self._apply()
+
+    def _lr(self, base):
+        c = self.cfg
+        if self.last_epoch < c.WARMUP_EPOCH and c.WARMUP_TYPE == "constant":
+            return c.WARMUP_CONS_LR
+        if c.LR_SCHEDULER == "cosine":
+            return 0.5 * base * (1 + math.cos(math.pi * self.last_epoch / c.MAX_EPOCH))
+        return base
+
+    def _apply(self):
+        for g, b in zip(self.optim.param_groups, self.base_lrs):
+            g["lr"] = self._lr(b)
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch, "base_lrs": self.base_lrs}
+
+    def load_state_dict(self, sd):
+        self.last_epoch, self.base_lrs = sd["last_epoch"], sd["base_lrs"]
+        self._apply()
+
+
+def build_lr_scheduler(optim, optim_cfg):
+    return _ConstantWarmupCosine(optim, optim_cfg)
+
+
+class TrainerX:
+    """The slice of dassl.engine.TrainerX the reference relies on."""
+
+    def __init__(self, cfg: CfgNode):
+        self._models, self._optims, self._scheds = OrderedDict(), OrderedDict(), OrderedDict()
+        self.cfg = cfg
+        self.rank, self.world_size, self.local_rank = dist_utils.rank_info()
+        self.device = torch.device(f"cuda:{self.local_rank}") if torch.cuda.is_available() else torch.device("cpu")
+        self.start_epoch = self.epoch = 0
+        self.max_epoch = cfg.OPTIM.MAX_EPOCH
+        self.output_dir = cfg.OUTPUT_DIR
+        self.batch_idx, self.num_batches = 0, 0
+        self.check_cfg(cfg)
+        self.build_data_loader()
+        self.build_model()
+
+    # -- registry / bookkeeping
+    def register_model(self, name="model", model=None, optim=None, sched=None):
+        self._models[name], self._optims[name], self._scheds[name] = model, optim, sched
+
+    def get_model_names(self, names=None):
+        return list(self._models.keys()) if names is None else list(names)
+
+    def set_model_mode(self, mode="train", names=None):
+        for n in self.get_model_names(names):
+            self._models[n].train(mode == "train")
+
+    def update_lr(self, names=None):
+        for n in self.get_model_names(names):
+            if self._scheds[n] is not None:
+                self._scheds[n].step()
+
+    def model_zero_grad(self, names=None):
+        for n in self.get_model_names(names):
+            if self._optims[n] is not None:
+                self._optims[n].zero_grad(set_to_none=False)
+
+    def model_backward(self, loss):
+        loss.backward()
+
+    def model_update(self, names=None):
+        for n in self.get_model_names(names):
+            if self._optims[n] is not None:
+                self._optims[n].step()
+
+    def model_backward_and_update(self, loss, names=None):
+        """Dassl order: zero_grad -> backward -> step.  The finite-loss check of Dassl's `detect_anomaly` is done
+        once per PRINT_FREQ on the host copy of the loss instead of forcing a device sync every step."""
+        self.model_zero_grad(names)
+        self.model_backward(loss)
+        self.sync_gradients(names)
+        self.model_update(names)
+
+    def sync_gradients(self, names=None):
+        if self.world_size > 1:
+            for n in self.get_model_names(names):
+                dist_utils.all_reduce_gradients(self._models[n].parameters(), self.world_size)
+
+    # -- checkpoints (Dassl format: state_dict, epoch, optimizer, scheduler, val_result)
+    def save_model(self, epoch, directory, is_best=False, val_result=None, model_name=""):
+        if self.rank != 0:
+            return
+        for n in self.get_model_names():
+            d = osp.join(directory, n)
+            os.makedirs(d, exist_ok=True)
+            ckpt = {"state_dict": self._models[n].state_dict(), "epoch": epoch + 1,
+                    "optimizer": None if self._optims[n] is None else self._optims[n].state_dict(),
+                    "scheduler": None if self._scheds[n] is None else self._scheds[n].state_dict(),
+                    "val_result": val_result}
+            fname = model_name or f"model.pth.tar-{epoch + 1}"
+            torch.save(ckpt, osp.join(d, fname))
+            if is_best:
+                torch.save(ckpt, osp.join(d, "model-best.pth.tar"))
+
+    # -- loop
+    def train(self):
+        for self.epoch in range(self.start_epoch, self.max_epoch):
+            self.run_epoch()
+            if self.epoch + 1 == self.max_epoch:
+                self.save_model(self.epoch, self.output_dir)
+
+    def run_epoch(self):
+        self.set_model_mode("train")
+        self.num_batches = len(self.train_loader_x)
+        t0 = time.time()
+        for self.batch_idx, batch in enumerate(self.train_loader_x):
+            summary = self.forward_backward(batch)
+            if (self.batch_idx + 1) % self.cfg.TRAIN.PRINT_FREQ == 0 and self.rank == 0:
+                vals = {k: (float(v) if torch.is_tensor(v) else v) for k, v in summary.items()}
+                if not math.isfinite(vals["loss"]):
+                    raise FloatingPointError("Loss is infinite or NaN!")
+                print(f"epoch [{self.epoch + 1}/{self.max_epoch}] batch [{self.batch_idx + 1}/{self.num_batches}] "
+                      f"time {time.time() - t0:.2f}s " + " ".join(f"{k} {v:.4f}" for k, v in vals.items()))
+
+    # hooks the concrete trainer provides
+    def check_cfg(self, cfg):
+        pass
+
+    def build_data_loader(self):
+        raise NotImplementedError
+
+    def build_model(self):
+        raise NotImplementedError
+
+    def forward_backward(self, batch):
+        raise NotImplementedError
+
+
+# ------------------------------------------------------------------------------------------------ synthetic data
+class SyntheticDataManager:
+    """Shape-contract stand-in for MVLPTCOOPDataManager (trainers/mvlpt.py:585-671): N(0,1) images, uniform labels,
+    optional task ids with labels drawn inside the task's class range."""
+
+    def __init__(self, cfg, num_classes: int, steps_per_epoch: int, task_class_counts=None, device="cpu", seed=1234,
+                 soft_labels=False):
+        self.num_classes = self._num_classes = num_classes
+        self.classnames = [f"class {i}" for i in range(num_classes)]
+        self.lab2cname = {i: n for i, n in enumerate(self.classnames)}
+        self.dataset = self
+        self.num_source_domains = 1
+        self._task_names, self._labelmap = [], {}
+        self.task_class_counts = task_class_counts
+        if task_class_counts:
+            self._task_names = [f"task{i}" for i in range(len(task_class_counts))]
+            self._labelmap = {n: list(range(c)) for n, c in zip(self._task_names, task_class_counts)}
+        B, R = cfg.DATALOADER.TRAIN_X.BATCH_SIZE, cfg.INPUT.SIZE[0]
+        g = torch.Generator().manual_seed(seed)
+        batches = []
+        for _ in range(steps_per_epoch):
+            img = torch.randn(B, 3, R, R, generator=g)
+            dom = torch.zeros(B, dtype=torch.long)
+            if task_class_counts:
+                dom = torch.randint(0, len(task_class_counts), (B,), generator=g)
+                starts = torch.tensor([0] + list(torch.tensor(task_class_counts).cumsum(0)[:-1]))
+                lab = starts[dom] + (torch.rand(B, generator=g) * torch.tensor(task_class_counts)[dom]).long()
+            else:
+                lab = torch.randint(0, num_classes, (B,), generator=g)
+            if soft_labels:
+                lab = torch.nn.functional.one_hot(lab, num_classes).float()
+            batches.append({"img": img.to(device), "label": lab.to(device), "domain": dom})
+        self.train_loader_x = batches
+        self.train_loader_u = self.val_loader = None
+        self.test_loader = batches[:1]
+
+
+# ------------------------------------------------------------------------------------------------ the trainer
+class MVLPT(TrainerX):
+    """trainers/mvlpt.py:827-1125 on the HIP engine."""
+
+    def __init__(self, cfg, dm=None, clip_state_dict=None):
+        self._dm_arg, self._sd_arg = dm, clip_state_dict
+        super().__init__(cfg)
+
+    def check_cfg(self, cfg):
+        assert cfg.TRAINER.MVLPT.PREC in ["fp16", "fp32", "amp"]        # :835-836
+
+    def build_data_loader(self):
+        self.multi_task = self.cfg.DATASET.MULTITASK
+        self.multi_task_label_pertask = self.cfg.DATASET.MULTITASK_LABEL_PERTASK
+        dm = self._dm_arg
+        if dm is None:
+            raise ValueError("pass a data manager (e.g. SyntheticDataManager); dataset readers are out of scope")
+        self.train_loader_x, self.train_loader_u = dm.train_loader_x, dm.train_loader_u
+        self.val_loader, self.test_loader = dm.val_loader, dm.test_loader
+        self.num_classes, self.num_source_domains, self.lab2cname = dm.num_classes, dm.num_source_domains, dm.lab2cname
+        self.dm = dm
+
+    def build_model(self):
+        cfg = self.cfg
+        classnames = self.dm.dataset.classnames if cfg.DATASET.COOP else list(self.dm.lab2cname.values())
+        sd = self._sd_arg
+        if sd is None:
+            # no network: synthetic frozen weights of the named architecture (clip/clip.py:57 would download)
+            sd = make_state_dict(ARCHS[cfg.MODEL.BACKBONE.NAME], seed=cfg.SEED)
+        clip_model = FrozenCLIP(sd, compute_dtype=cfg.TRAINER.MVLPT.COMPUTE_DTYPE, device=self.device)
+        self.model = CustomCLIP(cfg, classnames, clip_model, dm=self.dm)
+        for name, param in self.model.named_parameters():               # :855-858 (the towers hold no nn.Parameters)
+            if "prompt_learner" not in name:
+                param.requires_grad_(False)
+        if cfg.MODEL.INIT_WEIGHTS:
+            ck = torch.load(cfg.MODEL.INIT_WEIGHTS, map_location="cpu")
+            self.model.prompt_learner.load_state_dict(ck.get("state_dict", ck), strict=False)
+        self.model.to(self.device)
+        if self.world_size > 1:
+            dist_utils.broadcast_parameters(self.model.prompt_learner)   # identical prompts on every rank
+        self.optim = build_optimizer(self.model.prompt_learner, cfg.OPTIM)   # NOTE: only the prompt learner (:869)
+        self.sched = build_lr_scheduler(self.optim, cfg.OPTIM)
+        self.register_model("prompt_learner", self.model.prompt_learner, self.optim, self.sched)
+        self.scaler = None    # the HIP backward scales its 16-bit activation gradients internally
+
+    def forward_backward(self, batch):
+        image, label, tasks_ = self.parse_batch_train(batch)
+        if len(label.shape) > 1 and label.shape[-1] > 1:                # :914-916
+            label = label.float()
+            label = label / label.sum(dim=-1, keepdim=True)
+        output = self.model(image, task=tasks_)
+        loss = self.model.cross_entropy(output, label)                  # F.cross_entropy (:931) as a HIP kernel
+        self.model_backward_and_update(loss)
+        # device tensors: no .item() sync inside the step (the reference syncs twice per step, :941-942)
+        loss_summary = {"loss": loss.detach(), "acc": self.model.last_ncorrect[0] * (100.0 / output.shape[0])}
+        if tasks_ is not None:
+            loss_summary["num_tasks"] = len(set(tasks_.tolist()))
+        if (self.batch_idx + 1) == self.num_batches:
+            self.update_lr()
+        return loss_summary
+
+    def parse_batch_train(self, batch):
+        if self.cfg.DATASET.COOP:
+            inp_key, lab_key, task_key = "img", "label", "domain"
+        else:
+            inp_key, lab_key, task_key = 0, 1, 3
+        tasks = batch[task_key] if self.multi_task else None
+        return batch[inp_key].to(self.device), batch[lab_key].to(self.device), tasks
+
+    parse_batch_test = parse_batch_train
+
+    @torch.no_grad()
+    def model_inference(self, input, task=None):
+        return self.model(input, task=task)
+
+    def load_model(self, directory, epoch=None):
+        if not directory:
+            print("Note that load_model() is skipped as no pretrained model is given")
+            return
+        model_file = "model-best.pth.tar" if epoch is None else "model.pth.tar-" + str(epoch)
+        for name in self.get_model_names():
+            path = osp.join(directory, name, model_file)
+            if not osp.exists(path):
+                raise FileNotFoundError('Model not found at "{}"'.format(path))
+            ck = torch.load(path, map_location="cpu")
+            sd = {k.replace("upt_proj", "mvlpt_proj"): v for k, v in ck["state_dict"].items()}   # :1112
+            sd.pop("token_prefix", None)
+            sd.pop("token_suffix", None)
+            self._models[name].load_state_dict(sd, strict=False)

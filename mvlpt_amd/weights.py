@@ -68,10 +68,15 @@ def arch_from_state_dict(sd: Dict[str, torch.Tensor], name: str = "custom") -> C
                     sd["positional_embedding"].shape[0], vocab, tw, tw // 64, tl)
 
 
-def _randn(name: str, seed: int, shape, std: float) -> torch.Tensor:
+def _randn(name: str, seed: int, shape, std: float, fp16_exact: bool = False) -> torch.Tensor:
     h = int.from_bytes(hashlib.sha256(f"{seed}:{name}".encode()).digest()[:7], "little")
     g = torch.Generator(device="cpu").manual_seed(h)
-    return torch.randn(tuple(shape), generator=g, dtype=torch.float32) * std
+    w = torch.randn(tuple(shape), generator=g, dtype=torch.float32) * std
+    # Real CLIP checkpoints store conv/linear/attention/projection tensors in fp16 (clip/model.py:371-392
+    # convert_weights; "CLIP's default precision is fp16", trainers/mvlpt.py:849) and the fp32/amp modes only
+    # up-cast them: such values are exactly representable in fp16.  Mirror that so that parity measures the
+    # kernels' arithmetic and not a weight quantisation real checkpoints never undergo.
+    return w.half().float() if fp16_exact else w
 
 
 def make_state_dict(arch: ClipArch, seed: int = 0, *, include_token_embedding: bool = False,
@@ -89,7 +94,7 @@ def make_state_dict(arch: ClipArch, seed: int = 0, *, include_token_embedding: b
             sd[prefix + ".bias"] = torch.zeros(d)
 
     def bias(name: str, d: int):
-        sd[name] = _randn(name, seed, (d,), 0.02) if randomize_affine else torch.zeros(d)
+        sd[name] = _randn(name, seed, (d,), 0.02, True) if randomize_affine else torch.zeros(d)
 
     def tower(prefix: str, width: int, layers: int, init_width: int, init_layers: int):
         # clip/model.py:312-319 uses the TEXT transformer's width/layers for the text tower;
@@ -99,26 +104,26 @@ def make_state_dict(arch: ClipArch, seed: int = 0, *, include_token_embedding: b
         fc_std = (2 * init_width) ** -0.5
         for l in range(layers):
             p = f"{prefix}resblocks.{l}."
-            sd[p + "attn.in_proj_weight"] = _randn(p + "attn.in_proj_weight", seed, (3 * width, width), attn_std)
+            sd[p + "attn.in_proj_weight"] = _randn(p + "attn.in_proj_weight", seed, (3 * width, width), attn_std, True)
             bias(p + "attn.in_proj_bias", 3 * width)
-            sd[p + "attn.out_proj.weight"] = _randn(p + "attn.out_proj.weight", seed, (width, width), proj_std)
+            sd[p + "attn.out_proj.weight"] = _randn(p + "attn.out_proj.weight", seed, (width, width), proj_std, True)
             bias(p + "attn.out_proj.bias", width)
             affine(p + "ln_1", width)
-            sd[p + "mlp.c_fc.weight"] = _randn(p + "mlp.c_fc.weight", seed, (4 * width, width), fc_std)
+            sd[p + "mlp.c_fc.weight"] = _randn(p + "mlp.c_fc.weight", seed, (4 * width, width), fc_std, True)
             bias(p + "mlp.c_fc.bias", 4 * width)
-            sd[p + "mlp.c_proj.weight"] = _randn(p + "mlp.c_proj.weight", seed, (width, 4 * width), proj_std)
+            sd[p + "mlp.c_proj.weight"] = _randn(p + "mlp.c_proj.weight", seed, (width, 4 * width), proj_std, True)
             bias(p + "mlp.c_proj.bias", width)
             affine(p + "ln_2", width)
 
     vw, p = arch.vision_width, arch.vision_patch_size
     scale = vw ** -0.5
-    sd["visual.conv1.weight"] = _randn("visual.conv1.weight", seed, (vw, 3, p, p), (3 * p * p) ** -0.5)
+    sd["visual.conv1.weight"] = _randn("visual.conv1.weight", seed, (vw, 3, p, p), (3 * p * p) ** -0.5, True)
     sd["visual.class_embedding"] = _randn("visual.class_embedding", seed, (vw,), scale)
     sd["visual.positional_embedding"] = _randn("visual.positional_embedding", seed, (arch.grid ** 2 + 1, vw), scale)
     affine("visual.ln_pre", vw)
     tower("visual.transformer.", vw, arch.vision_layers, vw, arch.vision_layers)
     affine("visual.ln_post", vw)
-    sd["visual.proj"] = _randn("visual.proj", seed, (vw, arch.embed_dim), scale)
+    sd["visual.proj"] = _randn("visual.proj", seed, (vw, arch.embed_dim), scale, True)
 
     tw = arch.transformer_width
     tower("transformer.", tw, arch.transformer_layers, tw, arch.transformer_layers)
@@ -126,6 +131,6 @@ def make_state_dict(arch: ClipArch, seed: int = 0, *, include_token_embedding: b
         sd["token_embedding.weight"] = _randn("token_embedding.weight", seed, (arch.vocab_size, tw), 0.02)
     sd["positional_embedding"] = _randn("positional_embedding", seed, (arch.context_length, tw), 0.01)
     affine("ln_final", tw)
-    sd["text_projection"] = _randn("text_projection", seed, (tw, arch.embed_dim), tw ** -0.5)
+    sd["text_projection"] = _randn("text_projection", seed, (tw, arch.embed_dim), tw ** -0.5, True)
     sd["logit_scale"] = torch.tensor(math.log(1 / 0.07), dtype=torch.float32)  # clip/model.py:291
     return sd

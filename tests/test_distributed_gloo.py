@@ -1,0 +1,57 @@
+"""world_size-2 gloo test (CPU) of the only collective on the path: ONE flat all-reduce of the prompt gradients.
+Checks that rank-averaged gradients equal the gradient of the global-batch mean loss."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from mvlpt_amd import distributed as D
+    assert D.init_process_group("gloo") == (rank, world, rank)
+    torch.manual_seed(0)
+    # a stand-in "prompt learner": several parameters of different shapes (ctx, vpt, deep, projection)
+    params = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(s)) for s in [(16, 8), (1, 4, 8), (3, 4, 8), (5,)]])
+    if rank == 1:
+        with torch.no_grad():
+            for p in params:
+                p.add_(1.0)                      # ranks start different ...
+    D.broadcast_parameters(params)               # ... and must end identical to rank 0
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(8, 8, generator=g)           # global batch of 8, 4 per rank
+
+    def loss_fn(x):
+        h = x @ params[0].t()
+        return (h.sum(-1) * params[3].sum() + (params[1] * params[2][:1]).sum()).pow(2).mean()
+
+    loss_fn(X[rank * 4:(rank + 1) * 4]).backward()
+    D.all_reduce_gradients(params, world)
+    got = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    loss_fn(X).backward()                        # single-process reference on the concatenated batch
+    ok = all(torch.allclose(a, p.grad, rtol=1e-5, atol=1e-6) for a, p in zip(got, params))
+    mx = D.all_reduce_max(float(rank + 1), torch.device("cpu"))
+    D.barrier()
+    ret[rank] = bool(ok and mx == float(world))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_matches_global_batch():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
