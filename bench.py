@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--all-kernel-timing", action="store_true", help="bracket every kernel class with marker events (slower)")
     args = ap.parse_args()
 
     from mvlpt_amd import distributed as D
@@ -145,7 +146,7 @@ def main():
     torch.cuda.synchronize()
     timing = not args.no_kernel_timing
     if timing:
-        eng.profile_begin()
+        eng.profile_begin(all_kernels=args.all_kernel_timing)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)

@@ -92,7 +92,7 @@ int mvlpt_cross_entropy(void* handle, const float* logits, const void* labels, i
 
 /* ---- kernel-level entry points (what the parity tests call; same kernels the towers use) ------------------ */
 /* C[M,N] = A[M,K] * Bt[N,K]^T with epilogue `epi` (0 store16(+bias), 1 bias+QuickGELU (out2 = pre-activation),
- * 2 fp32 out = acc+bias+resid32, 3 out16 = acc*QuickGELU'(aux16), 4 fp32 store).  K % 64 == 0, N % 4 == 0. */
+ * 2 fp32 out = acc+bias+resid32, 3 out16 = acc*QuickGELU'(aux16), 4 fp32 store).  K % 64 == 0, N % 128 == 0. */
 int mvlpt_op_gemm(int dtype, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
                   const float* resid, void* out, void* out2, mvlpt_stream_t stream);
 int mvlpt_op_layernorm_fwd(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
@@ -114,7 +114,9 @@ typedef struct MvlptKernelStat {
   double flops; /* algorithmic FLOPs summed over launches (2*M*N*K for GEMM, 4*L*L*64 per head for attention) */
   double bytes; /* algorithmic HBM bytes summed over launches */
 } MvlptKernelStat;
-int mvlpt_profile_begin(void* handle);
+/* all_kernels == 0: only the dominant kernel (gemm_bt) is timed, through its own dispatch timestamps (no marker
+ * packets on the stream); != 0: every kernel class is bracketed by marker events (adds ~1.5 us per event). */
+int mvlpt_profile_begin(void* handle, int all_kernels);
 /* synchronises the recorded events, fills up to `max_stats` entries, returns the number written (or <0) */
 int mvlpt_profile_end(void* handle, MvlptKernelStat* stats, int max_stats);
 

@@ -10,9 +10,10 @@
 // softmax row-reduction is in-register plus two wavefront shuffles (xor 16, 32), and the P^T accumulator
 // registers ARE the B operand of the next MFMA (O^T = V^T P^T) with no cross-lane movement: the k-slot
 // (lane>>4)*8 + j of a 32-key block is defined as key 4*(lane>>4) + j of its first 16-key tile for j<4
-// and of its second tile for j>=4; V^T is staged in LDS in exactly that order (two ds_read_b64).
-// K rows are stored 128 B wide with the 16-B chunk index XOR (row & 7) (conflict-free ds_read_b128);
-// V^T rows are padded to (LP + 8) elements = 4*odd dwords (conflict-free ds_read_b64).
+// and of its second tile for j>=4.  K and V rows are stored 128 B wide with the 16-B chunk index XOR (row & 7)
+// (conflict-free ds_read_b128); the forward reads V^T fragments straight out of the row-major V image with the
+// hardware transpose read ds_read_b64_tr_b16; the backward kernels still stage explicit transposed copies
+// (rows padded to LP + 8 elements = 4*odd dwords, conflict-free ds_read_b64).
 #include "kernels.h"
 
 namespace mvlpt {
@@ -29,6 +30,19 @@ __device__ __forceinline__ void stage_rows(char* dst, const T* src, size_t ld, i
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < L) v = *(const uint4*)(src + (size_t)row * ld + c * 8);
     *(uint4*)(dst + row * 128 + ((c ^ (row & 7)) * 16)) = v;
+  }
+}
+// Same image filled by LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip, all slabs in flight at once):
+// one wave-instruction writes a lane-linear 1 KiB slab = 8 rows x 128 B, so the chunk swizzle is applied to the
+// per-lane SOURCE address.  Rows >= L re-read row L-1 (finite values; they only ever meet P = 0 / masked scores).
+// The caller waits with s_waitcnt vmcnt(0) + barrier before the first ds_read.
+template <typename T>
+__device__ __forceinline__ void stage_rows_dma(char* dst, const T* src, size_t ld, int L, int LP, int wave, int lane) {
+  const int srow = lane >> 3, chunk = (lane & 7) ^ srow;
+  for (int sl = wave; sl < LP / 8; sl += 4) {
+    int row = sl * 8 + srow;
+    row = row < L ? row : L - 1;
+    glds16(src + (size_t)row * ld + chunk * 8, dst + sl * 1024);
   }
 }
 // transposed [64][VS] image (VS = LP + 8), zero filled past L
@@ -68,6 +82,34 @@ __device__ __forceinline__ typename Vec<T>::v8 pack8(const f32x4& a, const f32x4
   for (int e = 0; e < 4; ++e) { r[e] = from_f32<T>(a[e]); r[e + 4] = from_f32<T>(b[e]); }
   return r;
 }
+// Hardware transpose read (gfx950 ds_read_b64_tr_b16).  Each lane passes the address of 4 contiguous 16-bit
+// elements; within a 16-lane group, lanes 4r..4r+3 supply row r (16 columns) of a 4x16 block and lane i receives
+// column i of that block (4 rows).  It turns a ROW-major [key][d] LDS image of V into the k-slot-major operand
+// the MFMA wants (lane = d column, elements = 4 consecutive keys) with no transposed staging pass.
+typedef __fp16 hv4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __bf16 bv4_t __attribute__((__vector_size__(4 * sizeof(__bf16))));
+template <typename T> __device__ __forceinline__ typename Vec<T>::v4 tr_read4(const char* p);
+template <> __device__ __forceinline__ f16x4 tr_read4<f16>(const char* p) {
+  hv4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hv4_t*)p);
+  return __builtin_bit_cast(f16x4, r);
+}
+template <> __device__ __forceinline__ bf16x4 tr_read4<bf16>(const char* p) {
+  bv4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bv4_t*)p);
+  return __builtin_bit_cast(bf16x4, r);
+}
+// A-operand fragment "V^T rows dt*16 + (lane&15), k-slots of 32-key block kb" out of the row-major swizzled V image
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::v8 frag_vt(const char* img, int kb, int dt, int fr, int fg) {
+  const int koff = fg * 4 + (fr >> 2);                  // key inside the 16-key tile supplied by this lane
+  const int chunk = (dt * 2 + ((fr & 3) >> 1)) ^ (koff & 7);
+  const char* p = img + (kb * 32 + koff) * 128 + chunk * 16 + (fr & 1) * 8;
+  const typename Vec<T>::v4 lo = tr_read4<T>(p);
+  const typename Vec<T>::v4 hi = tr_read4<T>(p + 16 * 128);   // second 16-key tile of the block (same key&7)
+  typename Vec<T>::v8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[e + 4] = hi[e]; }
+  return r;
+}
 __device__ __forceinline__ float quad_sum(float v) {  // reduce over the four lanes sharing lane&15
   v += __shfl_xor(v, 16, 64);
   v += __shfl_xor(v, 32, 64);
@@ -85,25 +127,39 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using v8 = typename Vec<T>::v8;
   using v4 = typename Vec<T>::v4;
-  constexpr int LP = NKT * 16, VS = LP + 8;
-  char* sK = smem;                            // [LP][64] swizzled
-  T* sVt = (T*)(smem + LP * 128);             // [64][VS]
+  constexpr int LP = NKT * 16;
+  char* sK = smem;                            // [LP][64] row-major, 16-B chunks swizzled by (row & 7)
+  char* sV = smem + LP * 128;                 // same image for V; transposed on the fly by ds_read_b64_tr_b16
   const int L = a.L, H = a.H, d = H * 64;
   const int n = blockIdx.x / H, h = blockIdx.x % H;
   const size_t ld = (size_t)3 * d;
   const T* base = (const T*)a.qkv + (size_t)n * L * ld + h * 64;
-  stage_rows<T>(sK, base + d, ld, L, LP);
-  stage_transposed<T>(sVt, base + 2 * d, ld, L, LP, VS);
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const int nqt = (L + 15) >> 4;
-  for (int qt = wave; qt < nqt; qt += 4) {
-    const int qrow = qt * 16 + fr;
-    const int qr = qrow < L ? qrow : L - 1;
+  // every Q fragment this wave will need is requested before the K/V DMA is waited for (one latency, not one per tile)
+  constexpr int MAXQ = (NKT + 3) / 4;
+  v8 qf[MAXQ][2];
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    int qr = (wave + 4 * i) * 16 + fr;
+    qr = qr < L ? qr : L - 1;
     const T* qp = base + (size_t)qr * ld + fg * 8;
-    const v8 q0 = *(const v8*)qp, q1 = *(const v8*)(qp + 32);
+    qf[i][0] = *(const v8*)qp;
+    qf[i][1] = *(const v8*)(qp + 32);
+  }
+  stage_rows_dma<T>(sK, base + d, ld, L, LP, wave, lane);
+  stage_rows_dma<T>(sV, base + 2 * d, ld, L, LP, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  constexpr float SC = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e): softmax in base 2
+#pragma unroll
+  for (int qi = 0; qi < MAXQ; ++qi) {
+    const int qt = wave + 4 * qi;
+    if (qt >= nqt) break;
+    const int qrow = qt * 16 + fr;
+    const v8 q0 = qf[qi][0], q1 = qf[qi][1];
     const int nkt = CAUSAL ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;   // key tiles that can be unmasked
     f32x4 s[NKT];
     float mx = -INFINITY;
@@ -117,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + fg * 4 + r;
           const bool ok = key < L && (!CAUSAL || key <= qrow);
-          s[kt][r] = ok ? s[kt][r] * 0.125f : -INFINITY;
+          s[kt][r] = ok ? s[kt][r] * SC : -INFINITY;
           mx = fmaxf(mx, s[kt][r]);
         }
       }
@@ -128,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nkt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - mx); sum += s[kt][r]; }
+        for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx); sum += s[kt][r]; }
       }
     }
     sum = quad_sum(sum);
@@ -141,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       if (2 * kb < nkt) {
         const v8 pf = pack8<T>(s[2 * kb], s[2 * kb + 1]);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16<T>(frag_transposed<T>(sVt, VS, dt, kb, fr, fg), pf, o[dt]);
+        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16<T>(frag_vt<T>(sV, kb, dt, fr, fg), pf, o[dt]);
       }
     }
     if (qrow < L) {
@@ -153,7 +209,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(o[dt][e] * inv);
         *(v4*)(op + dt * 16) = w;
       }
-      if (a.lse && fg == 0) a.lse[((size_t)n * H + h) * L + qrow] = mx + __logf(sum);
+      // natural-log LSE of the scaled scores (the backward recomputes P = exp(s/8 - lse))
+      if (a.lse && fg == 0) a.lse[((size_t)n * H + h) * L + qrow] = (mx + log2f(sum)) * 0.6931471805599453f;
     }
   }
 }
@@ -340,8 +397,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
 // ======================================================================================= launchers
 template <typename T, int NKT, bool CAUSAL>
 static hipError_t fwd_t(const AttnArgs& a, hipStream_t s) {
-  constexpr int LP = NKT * 16, VS = LP + 8;
-  constexpr int lds = LP * 128 + 64 * VS * 2;
+  constexpr int LP = NKT * 16;
+  constexpr int lds = 2 * LP * 128;
   static bool set = false;
   if (!set) { hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
   hipLaunchKernelGGL((attn_fwd_kernel<T, NKT, CAUSAL>), dim3(a.N * a.H), dim3(256), lds, s, a);

@@ -6,181 +6,309 @@
 // stores W as [N,K] so the forward reads it as-is; the dX GEMM reads the pre-transposed copy packed
 // once at load time (weights are frozen, trainers/mvlpt.py:855-858).
 //
-// gfx950 design: 128x128x64 tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32
-// accumulators (fp32).  A/B tiles go HBM -> LDS with 16-byte LDS-DMA (global_load_lds), double
-// buffered.  The LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle is applied to
+// gfx950 design: one kernel template, two geometries.  Every wave owns a 64x64 output block = 4x4 MFMA
+// 16x16x32 accumulators (fp32); BK = 64.
+//   big   : 256x128 tile, 512 threads = 8 waves (4x2), ONE workgroup per CU, 3-deep LDS ring (144 KiB) with
+//           COUNTED s_waitcnt vmcnt: the loads of K-stage f+2 stay in flight across the barrier that ends
+//           stage f (raw s_barrier + lgkmcnt(0), never __syncthreads, which would drain the DMA queue).
+//   small : 128x128 tile, 256 threads = 4 waves (2x2), two workgroups per CU, 2-deep ring, for GEMMs with too
+//           few 256x128 tiles to fill 256 CUs (the text tower, CLS-row projections).
+// A/B tiles go HBM -> LDS with 16-byte LDS-DMA (global_load_lds).  The LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle is applied to
 // the per-lane SOURCE address and undone on the ds_read_b128 side: 16-byte chunk c of tile row r lives
 // at chunk (c ^ (r & 7)).  MFMA operands are swapped (D = Bfrag x Afrag) so each lane ends up with four
 // consecutive output COLUMNS of one row -> 8/16-byte epilogue stores, float4 bias loads.
 // Workgroups are remapped so that consecutive tiles (sharing an A panel) run on the same XCD/L2.
+#include <cstdlib>
+#include <hip/hip_ext.h>
 #include "kernels.h"
 
 namespace mvlpt {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // double buffered: 64 KiB -> 2 workgroups / CU
+constexpr int BN = 128, BK = 64;
+
+// Epilogue: the MFMA result layout gives every lane 4 consecutive columns of 16 different rows, i.e. 8-byte
+// pieces scattered over 16 rows per store instruction.  With ~0.8 GFLOP per MB of output (short K) the L2
+// request rate of such stores bounds the kernel, so each wave transposes its 64x64 block through a private LDS
+// scratch (the ring slot that has just been released) and writes / reads global memory in full 128-256-byte
+// row segments (16 B per lane).  fp16 outputs are staged as 16-bit, 32 rows per pass; everything that is
+// combined with another global operand in fp32 (residual, GELU' * u) is staged as fp32, 16 rows per pass.
+constexpr int EPI_SCRATCH_PER_WAVE = 4608;   // 32 rows x (128 + 16) B  >=  16 rows x (256 + 16) B
 
 template <typename T, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bt_kernel(GemmArgs g) {
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&acc)[4][4], int mbase, int nbase, int lane,
+                                               char* scratch /* wave-private, 16-B aligned */) {
+  using v4 = typename Vec<T>::v4;
+  using v8 = typename Vec<T>::v8;
+  const int M = g.M, N = g.N;      // N % 128 == 0 (checked at launch): no column guard
+  const int fr = lane & 15, fg = lane >> 4;
+  f32x4 bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (g.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + nbase + j * 16 + fg * 4);
+  }
+  if constexpr (EPI == EPI_STORE16 || EPI == EPI_GELU) {
+    constexpr int RS = 144;                                   // scratch row stride (bytes)
+    constexpr int NOUT = (EPI == EPI_GELU) ? 2 : 1;
+#pragma unroll
+    for (int which = 0; which < NOUT; ++which) {
+      // which == 0: the main output (activated for EPI_GELU); which == 1: the saved pre-activation u
+      T* outp = (T*)(which == 0 ? g.out : g.out2);
+      if (which == 1 && !outp) break;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int i = half * 2 + ii;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 v = acc[i][j] + bv[j];
+            v4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = from_f32<T>((EPI == EPI_GELU && which == 0) ? quick_gelu(v[e]) : v[e]);
+            *(v4*)(scratch + (ii * 16 + fr) * RS + (j * 16 + fg * 4) * 2) = w;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int r = it * 8 + (lane >> 3), c = lane & 7;   // 8 lanes x 16 B = one 128-B row segment
+          const v8 w = *(const v8*)(scratch + r * RS + c * 16);
+          const int m = mbase + half * 32 + r;
+          if (m < M) *(v8*)(outp + (size_t)m * N + nbase + c * 8) = w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // scratch is rewritten by the next pass
+      }
+    }
+  } else {
+    constexpr int RS = 272;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(scratch + fr * RS + (j * 16 + fg * 4) * 4) = acc[i][j] + bv[j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      f32x4 v[4];
+      int mrow[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 4 + (lane >> 4), c = lane & 15;    // 16 lanes x 16 B = one 256-B row segment (fp32)
+        v[it] = *(const f32x4*)(scratch + r * RS + c * 16);
+        mrow[it] = mbase + i * 16 + r;
+      }
+      const int c = lane & 15;
+      if constexpr (EPI == EPI_RESID32) {
+        f32x4 rv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int ml = mrow[it] < M ? mrow[it] : M - 1;
+          rv[it] = *(const f32x4*)(g.resid + (size_t)ml * N + nbase + c * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          if (mrow[it] < M) *(f32x4*)((float*)g.out + (size_t)mrow[it] * N + nbase + c * 4) = v[it] + rv[it];
+      } else if constexpr (EPI == EPI_GELUBWD) {
+        v4 uv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int ml = mrow[it] < M ? mrow[it] : M - 1;
+          uv[it] = *(const v4*)((const T*)g.aux + (size_t)ml * N + nbase + c * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          v4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(v[it][e] * quick_gelu_grad(to_f32<T>(uv[it][e])));
+          if (mrow[it] < M) *(v4*)((T*)g.out + (size_t)mrow[it] * N + nbase + c * 4) = w;
+        }
+      } else {  // EPI_STORE32
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          if (mrow[it] < M) *(f32x4*)((float*)g.out + (size_t)mrow[it] * N + nbase + c * 4) = v[it];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+// BM_ x 128 tile, NW waves arranged (NW/2) x 2, NS-deep LDS ring.  Persistent: gridDim.x resident workgroups walk
+// the tile list in rounds and keep the LDS-DMA pipeline running ACROSS tile boundaries (the first K-stages of the
+// next tile are in flight while the current tile finishes and its epilogue is stored), so the short-K GEMMs of
+// this path (K = 768 / 512) do not pay a load bubble per tile.
+template <typename T, int EPI, int BM_, int NW, int NS>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void gemm_bt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using v8 = typename Vec<T>::v8;
-  using v4 = typename Vec<T>::v4;
+  constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_IT = BM_ / 8 / NW, B_IT = BN / 8 / NW, LOADS = A_IT + B_IT;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = g.M, N = g.N, K = g.K;
-
-  // XCD-aware bijective remap: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles.
-  const int nwg = gridDim.x, b = blockIdx.x;
-  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
-  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  const int tilesN = (N + BN - 1) / BN;
-  const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
-
   const T* __restrict__ A = (const T*)g.A;
   const T* __restrict__ Bt = (const T*)g.Bt;
 
-  // ---- staging: thread -> (row, 16B chunk) of a 1 KiB LDS slab (8 rows x 128 B) ------------------
-  const int srow = lane >> 3;                       // row inside the slab == (tile row & 7)
-  const int scol = ((lane & 7) ^ srow) * 8;         // SOURCE chunk (elements) for LDS chunk lane&7
-  const T* ap[4];
-  const T* bp[4];
+  // XCD-aware order: workgroup b runs on XCD b%8; inside a full round each XCD gets G/8 consecutive tiles
+  // (tiles are N-fastest, so neighbours share their A panel in that XCD's L2).
+  const int G = gridDim.x, b = blockIdx.x;
+  const int tilesN = (N + BN - 1) / BN;
+  const int ntiles = ((M + BM_ - 1) / BM_) * tilesN;
+  const int gq = G >> 3, gr = G & 7, xcd = b & 7;
+  const int b_remap = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (b >> 3);
+  auto tile_of = [&](int round) -> int {
+    const int base = round * G;
+    return base + ((base + G <= ntiles) ? b_remap : b);   // ragged last round: plain order keeps XCDs balanced
+  };
+
+  // ---- staging: thread -> (row, 16B chunk) of a 1 KiB LDS slab (8 rows x 128 B); the LDS image is lane-linear,
+  //      so the bank swizzle is applied to the SOURCE column: LDS chunk c of row r holds source chunk c ^ (r & 7)
+  const int srow = lane >> 3;
+  const int scol = ((lane & 7) ^ srow) * 8;
+  const T* ap[A_IT];
+  const T* bp[B_IT];
+  auto set_ptrs = [&](int t) {
+    const int m0 = (t / tilesN) * BM_, n0 = (t % tilesN) * BN;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (i * 4 + wave) * 8 + srow;
-    int ar = m0 + row; ar = ar < M ? ar : M - 1;    // edge tiles: re-read the last row (never stored)
-    int br = n0 + row; br = br < N ? br : N - 1;
-    ap[i] = A + (size_t)ar * K + scol;
-    bp[i] = Bt + (size_t)br * K + scol;
-  }
-  auto stage = [&](int s, int kt) {
-    char* base = smem + s * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(ap[i] + kt * BK, base + (i * 4 + wave) * 1024);
-      glds16(bp[i] + kt * BK, base + TILE_BYTES + (i * 4 + wave) * 1024);
+    for (int i = 0; i < A_IT; ++i) {
+      int ar = m0 + (i * NW + wave) * 8 + srow; ar = ar < M ? ar : M - 1;   // edge rows are re-read, never stored
+      ap[i] = A + (size_t)ar * K + scol;
     }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int br = n0 + (i * NW + wave) * 8 + srow; br = br < N ? br : N - 1;
+      bp[i] = Bt + (size_t)br * K + scol;
+    }
+  };
+  // load cursor (runs NS-1 K-stages ahead of the compute cursor, across tile boundaries)
+  const int nk = K / BK;
+  int lround = 0, lt = tile_of(0), lkt = 0, lslot = 0;
+  if (lt >= ntiles) return;
+  set_ptrs(lt);
+  auto issue = [&]() -> bool {
+    if (lt >= ntiles) return false;
+    char* base = smem + lslot * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) glds16(ap[i] + lkt * BK, base + (i * NW + wave) * 1024);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) glds16(bp[i] + lkt * BK, base + A_BYTES + (i * NW + wave) * 1024);
+    lslot = lslot + 1 == NS ? 0 : lslot + 1;
+    if (++lkt == nk) {
+      lkt = 0;
+      lt = tile_of(++lround);
+      if (lt < ntiles) set_ptrs(lt);
+    }
+    return true;
   };
 
   // ---- fragment addressing ------------------------------------------------------------------------
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fg = lane >> 4;
-  const int a_off = (wm * 64 + fr) * 128;           // + i*16*128
-  const int b_off = TILE_BYTES + (wn * 64 + fr) * 128;
+  const int a_off = (wm * 64 + fr) * 128;
+  const int b_off = A_BYTES + (wn * 64 + fr) * 128;
   const int c0 = ((0 + fg) ^ (fr & 7)) * 16;        // k-step 0 chunk
   const int c1 = ((4 + fg) ^ (fr & 7)) * 16;        // k-step 1 chunk
 
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = K / BK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* base = smem + cur * STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int c = ks ? c1 : c0;
-      v8 af[4], bf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = *(const v8*)(base + a_off + i * 2048 + c);
-        bf[i] = *(const v8*)(base + b_off + i * 2048 + c);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(bf[j], af[i], acc[i][j]);
-    }
+  // prologue: fill NS-1 ring slots, wait for the first
+  bool more = issue();
+  if constexpr (NS == 3) {
+    more = issue();
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
+  __builtin_amdgcn_s_barrier();
 
-  // ---- epilogue: lane holds C[m = .. + fr][n = .. + 4*fg + 0..3] -------------------------------------
+  int slot = 0;
+  int t = tile_of(0);
+  for (int round = 0; t < ntiles; t = tile_of(++round)) {
+    f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fr;
-    if (m >= M) continue;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fg * 4;
-      if (n >= N) continue;
-      f32x4 v = acc[i][j];
-      if (g.bias) {
-        const f32x4 bv = *(const f32x4*)(g.bias + n);
-        v += bv;
-      }
-      const size_t o = (size_t)m * N + n;
-      if constexpr (EPI == EPI_STORE16) {
-        v4 w;
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool issued = issue();                  // K-stage f + NS - 1 -> the slot freed by the last barrier
+      const char* base = smem + slot * STAGE;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(v[e]);
-        *(v4*)((T*)g.out + o) = w;
-      } else if constexpr (EPI == EPI_GELU) {
-        v4 w;
-        if (g.out2) {
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = ks ? c1 : c0;
+        v8 af[4], bf[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(v[e]);
-          *(v4*)((T*)g.out2 + o) = w;
+        for (int i = 0; i < 4; ++i) {
+          af[i] = *(const v8*)(base + a_off + i * 2048 + c);
+          bf[i] = *(const v8*)(base + b_off + i * 2048 + c);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(quick_gelu(v[e]));
-        *(v4*)((T*)g.out + o) = w;
-      } else if constexpr (EPI == EPI_RESID32) {
-        const f32x4 rv = *(const f32x4*)(g.resid + o);
-        *(f32x4*)((float*)g.out + o) = v + rv;
-      } else if constexpr (EPI == EPI_GELUBWD) {
-        const v4 u = *(const v4*)((const T*)g.aux + o);
-        v4 w;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(v[e] * quick_gelu_grad(to_f32<T>(u[e])));
-        *(v4*)((T*)g.out + o) = w;
-      } else {  // EPI_STORE32
-        *(f32x4*)((float*)g.out + o) = v;
+          for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(bf[j], af[i], acc[i][j]);
       }
+      // the NEXT stage must have landed (own loads) before the barrier; the one just issued may stay in flight
+      if (NS == 3 && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      slot = slot + 1 == NS ? 0 : slot + 1;
     }
+    // the slot the load cursor will fill next has just been released by the barrier above: use it as scratch,
+    // and fence the scratch reads of all waves against that DMA with one more barrier
+    epilogue_store<T, EPI>(g, acc, (t / tilesN) * BM_ + wm * 64, (t % tilesN) * BN + wn * 64, lane,
+                           smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE);
+    __builtin_amdgcn_s_barrier();
   }
 }
 
-template <typename T, int EPI>
-static hipError_t launch_t(const GemmArgs& g, hipStream_t s) {
+template <typename T, int EPI, int BM_, int NW, int NS>
+static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  constexpr int LDS = NS * (BM_ + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, NW, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_bt_kernel<T, EPI>), dim3(tiles), dim3(256), GEMM_LDS, s, g);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN - 1) / BN);
+  const int resident = cus * wg_per_cu;
+  hipExtLaunchKernelGGL((gemm_bt_kernel<T, EPI, BM_, NW, NS>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), LDS, s,
+                        ea, eb, 0, g);
   return hipGetLastError();
 }
 
+template <typename T, int EPI>
+static hipError_t launch_t(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  // big geometry when its tiles fill the chip at least ~1.5 times; otherwise the 128x128 geometry
+  const long big_tiles = (long)((g.M + 255) / 256) * ((g.N + BN - 1) / BN);
+  static const int use_big = getenv("MVLPT_GEMM_BIG") ? atoi(getenv("MVLPT_GEMM_BIG")) : 1;   // experiment switch
+  if (big_tiles >= 384 && use_big) return launch_geo<T, EPI, 256, 8, 3>(g, 1, s, ea, eb);
+  return launch_geo<T, EPI, 128, 4, 2>(g, 2, s, ea, eb);
+}
+
 template <typename T>
-static hipError_t launch_epi(const GemmArgs& g, int epi, hipStream_t s) {
+static hipError_t launch_epi(const GemmArgs& g, int epi, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
   switch (epi) {
-    case EPI_STORE16: return launch_t<T, EPI_STORE16>(g, s);
-    case EPI_GELU: return launch_t<T, EPI_GELU>(g, s);
-    case EPI_RESID32: return launch_t<T, EPI_RESID32>(g, s);
-    case EPI_GELUBWD: return launch_t<T, EPI_GELUBWD>(g, s);
-    case EPI_STORE32: return launch_t<T, EPI_STORE32>(g, s);
+    case EPI_STORE16: return launch_t<T, EPI_STORE16>(g, s, ea, eb);
+    case EPI_GELU: return launch_t<T, EPI_GELU>(g, s, ea, eb);
+    case EPI_RESID32: return launch_t<T, EPI_RESID32>(g, s, ea, eb);
+    case EPI_GELUBWD: return launch_t<T, EPI_GELUBWD>(g, s, ea, eb);
+    case EPI_STORE32: return launch_t<T, EPI_STORE32>(g, s, ea, eb);
   }
   return hipErrorInvalidValue;
 }
 
-// K must be a multiple of 64 and N of 4 (callers pad); M is arbitrary.
-hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s) {
-  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N % 4) != 0) return hipErrorInvalidValue;
+// K must be a multiple of 64 and N of 128 (every CLIP width is; conv K is zero-padded); M is arbitrary.
+hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N % BN) != 0) return hipErrorInvalidValue;
   if (epi == EPI_RESID32 && !g.resid) return hipErrorInvalidValue;
   if (epi == EPI_GELUBWD && !g.aux) return hipErrorInvalidValue;
-  if (dtype == DT_F16) return launch_epi<f16>(g, epi, s);
-  if (dtype == DT_BF16) return launch_epi<bf16>(g, epi, s);
+  if (dtype == DT_F16) return launch_epi<f16>(g, epi, s, ea, eb);
+  if (dtype == DT_BF16) return launch_epi<bf16>(g, epi, s, ea, eb);
   return hipErrorInvalidValue;
 }
 

@@ -23,7 +23,10 @@ struct GemmArgs {
   void* out;           // [M,N]
   void* out2;          // [M,N] 16-bit, optional (EPI_GELU)
 };
-hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s);
+// ev_start/ev_stop (optional): recorded by the dispatch itself (hipExtLaunchKernelGGL): kernel-exact timing with no
+// extra marker packets on the stream.
+hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hipEvent_t ev_start = nullptr,
+                       hipEvent_t ev_stop = nullptr);
 
 // fp32 GEMM on the f32-input MFMA (exact f32 products, v_mfma_f32_16x16x4_f32) for the two tiny projections
 // next to the logits (CLS / EOT rows only): C[M,N] = alpha * A[M,K] * Bt[N,K]^T.  K % 16 == 0, N % 4 == 0.

@@ -195,8 +195,8 @@ class Engine:
         return loss, dl, nc
 
     # ------------------------------------------------------------------ profiling
-    def profile_begin(self):
-        _lib.check(lib.mvlpt_profile_begin(self.h), self.h, "profile_begin")
+    def profile_begin(self, all_kernels: bool = False):
+        _lib.check(lib.mvlpt_profile_begin(self.h, int(all_kernels)), self.h, "profile_begin")
 
     def profile_end(self) -> Dict[str, dict]:
         arr = (_lib.MvlptKernelStat * 16)()

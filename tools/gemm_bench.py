@@ -24,7 +24,9 @@ def bench(M, N, K, epi=0, iters=20, dtype=torch.float16):
 shapes = [(50432, 2304, 768, 0), (50432, 768, 768, 2), (50432, 3072, 768, 1), (50432, 768, 3072, 2),
           (7700, 1536, 512, 0), (7700, 512, 512, 2), (7700, 2048, 512, 1), (7700, 512, 2048, 2),
           (7700, 2048, 512, 3), (7700, 512, 1536, 4), (8192, 8192, 8192, 0), (4096, 4096, 4096, 0)]
-tot = 0
+if len(sys.argv) > 1:      # e.g. "50432,2304,768,0;4096,4096,4096,0" [iters]
+    shapes = [tuple(int(x) for x in sh.split(",")) for sh in sys.argv[1].split(";")]
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 for M, N, K, epi in shapes:
-    ms, tf = bench(M, N, K, epi)
+    ms, tf = bench(M, N, K, epi, iters)
     print(f"M={M:6d} N={N:5d} K={K:5d} epi={epi}: {ms*1e3:8.1f} us  {tf:7.1f} TF")
