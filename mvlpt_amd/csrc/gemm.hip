@@ -83,48 +83,44 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
     }
   } else {
     constexpr int RS = 272;
+    const int c = lane & 15, rq = lane >> 4;                  // 16 lanes x 16 B = one 256-B row segment (fp32)
+    // Every global LOAD of the epilogue is issued before its first store: hipcc waits vmcnt(0) on an ordinary
+    // load while LDS-DMA is in flight, and that wait would also drain the stores issued before it.
+    f32x4 rv[4][4];
+    v4 uv[4][4];
+    if constexpr (EPI == EPI_RESID32 || EPI == EPI_GELUBWD) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          int m = mbase + i * 16 + it * 4 + rq;
+          m = m < M ? m : M - 1;
+          if constexpr (EPI == EPI_RESID32) rv[i][it] = *(const f32x4*)(g.resid + (size_t)m * N + nbase + c * 4);
+          else uv[i][it] = *(const v4*)((const T*)g.aux + (size_t)m * N + nbase + c * 4);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) *(f32x4*)(scratch + fr * RS + (j * 16 + fg * 4) * 4) = acc[i][j] + bv[j];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      f32x4 v[4];
-      int mrow[4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int r = it * 4 + (lane >> 4), c = lane & 15;    // 16 lanes x 16 B = one 256-B row segment (fp32)
-        v[it] = *(const f32x4*)(scratch + r * RS + c * 16);
-        mrow[it] = mbase + i * 16 + r;
-      }
-      const int c = lane & 15;
-      if constexpr (EPI == EPI_RESID32) {
-        f32x4 rv[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int ml = mrow[it] < M ? mrow[it] : M - 1;
-          rv[it] = *(const f32x4*)(g.resid + (size_t)ml * N + nbase + c * 4);
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-          if (mrow[it] < M) *(f32x4*)((float*)g.out + (size_t)mrow[it] * N + nbase + c * 4) = v[it] + rv[it];
-      } else if constexpr (EPI == EPI_GELUBWD) {
-        v4 uv[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int ml = mrow[it] < M ? mrow[it] : M - 1;
-          uv[it] = *(const v4*)((const T*)g.aux + (size_t)ml * N + nbase + c * 4);
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        const int r = it * 4 + rq;
+        f32x4 v = *(const f32x4*)(scratch + r * RS + c * 16);
+        const int m = mbase + i * 16 + r;
+        const size_t o = (size_t)m * N + nbase + c * 4;
+        if constexpr (EPI == EPI_RESID32) {
+          v += rv[i][it];
+          if (m < M) *(f32x4*)((float*)g.out + o) = v;
+        } else if constexpr (EPI == EPI_GELUBWD) {
           v4 w;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(v[it][e] * quick_gelu_grad(to_f32<T>(uv[it][e])));
-          if (mrow[it] < M) *(v4*)((T*)g.out + (size_t)mrow[it] * N + nbase + c * 4) = w;
+          for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(v[e] * quick_gelu_grad(to_f32<T>(uv[i][it][e])));
+          if (m < M) *(v4*)((T*)g.out + o) = w;
+        } else {  // EPI_STORE32
+          if (m < M) *(f32x4*)((float*)g.out + o) = v;
         }
-      } else {  // EPI_STORE32
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-          if (mrow[it] < M) *(f32x4*)((float*)g.out + (size_t)mrow[it] * N + nbase + c * 4) = v[it];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -229,7 +225,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void gemm_bt_kernel(GemmA
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nk; ++kt) {
-      const bool issued = issue();                  // K-stage f + NS - 1 -> the slot freed by the last barrier
+      // K-stage f + NS - 1 goes to the slot freed by the last barrier.  An LDS-DMA instruction costs its wave
+      // ~100 issue cycles, as much per K-stage as the wave's 32 MFMAs; with two waves per SIMD (8-wave geometry)
+      // the older wave issues its DMA BEFORE its MFMAs and the younger one AFTER, so on every SIMD one wave
+      // multiplies while its partner is busy with the memory pipe instead of both doing the same thing.
+      const bool dma_first = (NW == 4) || (wave < NW / 2);
+      bool issued = false;
+      if (dma_first) issued = issue();
       const char* base = smem + slot * STAGE;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void gemm_bt_kernel(GemmA
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(bf[j], af[i], acc[i][j]);
       }
+      if (!dma_first) issued = issue();
       // the NEXT stage must have landed (own loads) before the barrier; the one just issued may stay in flight
       if (NS == 3 && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
