@@ -12,8 +12,9 @@
 // (lane>>4)*8 + j of a 32-key block is defined as key 4*(lane>>4) + j of its first 16-key tile for j<4
 // and of its second tile for j>=4.  K and V rows are stored 128 B wide with the 16-B chunk index XOR (row & 7)
 // (conflict-free ds_read_b128); the forward reads V^T fragments straight out of the row-major V image with the
-// hardware transpose read ds_read_b64_tr_b16; the backward kernels still stage explicit transposed copies
-// (rows padded to LP + 8 elements = 4*odd dwords, conflict-free ds_read_b64).
+// hardware transpose read ds_read_b64_tr_b16 (and so do the backward kernels for K^T, Q^T, dO^T): no transposed
+// copies are ever staged.  All LDS images are filled by LDS-DMA; per-wave Q/K/V/dO fragments that are used as B
+// operands are fetched from global memory once, before the DMA wait.
 #include "kernels.h"
 
 namespace mvlpt {
@@ -22,17 +23,8 @@ constexpr int ATT_MAX_NKT = 16;  // 16 tiles * 16 keys = 256
 int attn_max_len() { return ATT_MAX_NKT * 16; }
 
 // ---- staging helpers -------------------------------------------------------------------------------------
-// row-major [LP][64] 16-bit image, chunk-swizzled; rows >= L zero filled.  src: row stride `ld` elements.
-template <typename T>
-__device__ __forceinline__ void stage_rows(char* dst, const T* src, size_t ld, int L, int LP) {
-  for (int idx = threadIdx.x; idx < LP * 8; idx += 256) {
-    const int row = idx >> 3, c = idx & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < L) v = *(const uint4*)(src + (size_t)row * ld + c * 8);
-    *(uint4*)(dst + row * 128 + ((c ^ (row & 7)) * 16)) = v;
-  }
-}
-// Same image filled by LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip, all slabs in flight at once):
+// Row-major [LP][64] 16-bit LDS image with 128-B rows whose 16-B chunks are XOR-swizzled by (row & 7), filled by
+// LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip, all slabs in flight at once):
 // one wave-instruction writes a lane-linear 1 KiB slab = 8 rows x 128 B, so the chunk swizzle is applied to the
 // per-lane SOURCE address.  Rows >= L re-read row L-1 (finite values; they only ever meet P = 0 / masked scores).
 // The caller waits with s_waitcnt vmcnt(0) + barrier before the first ds_read.
@@ -45,35 +37,10 @@ __device__ __forceinline__ void stage_rows_dma(char* dst, const T* src, size_t l
     glds16(src + (size_t)row * ld + chunk * 8, dst + sl * 1024);
   }
 }
-// transposed [64][VS] image (VS = LP + 8), zero filled past L
-template <typename T>
-__device__ __forceinline__ void stage_transposed(T* dst, const T* src, size_t ld, int L, int LP, int VS) {
-  // consecutive lanes take consecutive ROWS of one 16-B column chunk: the 2-byte LDS writes of a wave
-  // then fall on consecutive addresses (the row-major mapping would put 8 lanes on one bank, 8-way)
-  for (int idx = threadIdx.x; idx < LP * 8; idx += 256) {
-    const int row = idx % LP, c = idx / LP;
-    typename Vec<T>::v8 v;
-    if (row < L) v = *(const typename Vec<T>::v8*)(src + (size_t)row * ld + c * 8);
-    else for (int e = 0; e < 8; ++e) v[e] = (T)0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dst[(c * 8 + e) * VS + row] = v[e];
-  }
-}
 // A-operand fragment of a row-major swizzled image: rows tile*16 + (lane&15), k-step ks (32 wide)
 template <typename T>
 __device__ __forceinline__ typename Vec<T>::v8 frag_rows(const char* img, int tile, int ks, int fr, int fg) {
   return *(const typename Vec<T>::v8*)(img + (tile * 16 + fr) * 128 + (((ks * 4 + fg) ^ (fr & 7)) * 16));
-}
-// A-operand fragment of a transposed image: row (dt*16 + lane&15), k-slots = 32-key block kb
-template <typename T>
-__device__ __forceinline__ typename Vec<T>::v8 frag_transposed(const T* img, int VS, int dt, int kb, int fr, int fg) {
-  const T* p = img + (dt * 16 + fr) * VS + kb * 32 + fg * 4;
-  const typename Vec<T>::v4 lo = *(const typename Vec<T>::v4*)p;
-  const typename Vec<T>::v4 hi = *(const typename Vec<T>::v4*)(p + 16);
-  typename Vec<T>::v8 r;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[e + 4] = hi[e]; }
-  return r;
 }
 template <typename T>
 __device__ __forceinline__ typename Vec<T>::v8 pack8(const f32x4& a, const f32x4& b) {
@@ -217,44 +184,55 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
 // ======================================================================================= backward A: dQ (+ delta)
 // per query tile:  S^T, P^T = exp(S^T*scale - lse), dP^T = V dO^T, dS^T = P^T (dP^T - delta) * scale,
-//                  dQ^T = K^T dS^T.   LDS: K rows, V rows, K transposed.
+//                  dQ^T = K^T dS^T.   LDS: K rows, V rows (DMA-staged); K^T fragments by transpose-read.
 template <typename T, int NKT, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using v8 = typename Vec<T>::v8;
   using v4 = typename Vec<T>::v4;
-  constexpr int LP = NKT * 16, VS = LP + 8;
+  constexpr int LP = NKT * 16;
+  constexpr int MAXQ = (NKT + 3) / 4;
   char* sK = smem;
   char* sV = smem + LP * 128;
-  T* sKt = (T*)(smem + 2 * LP * 128);
   const int L = a.L, H = a.H, d = H * 64;
   const int n = blockIdx.x / H, h = blockIdx.x % H;
   const size_t ld = (size_t)3 * d;
   const T* base = (const T*)a.qkv + (size_t)n * L * ld + h * 64;
-  stage_rows<T>(sK, base + d, ld, L, LP);
-  stage_rows<T>(sV, base + 2 * d, ld, L, LP);
-  stage_transposed<T>(sKt, base + d, ld, L, LP, VS);
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const int nqt = (L + 15) >> 4;
-  for (int qt = wave; qt < nqt; qt += 4) {
-    const int qrow = qt * 16 + fr;
-    const int qr = qrow < L ? qrow : L - 1;
+
+  // per-wave operands straight from global, requested before the K/V DMA is waited for
+  v8 qf[MAXQ][2], dof[MAXQ][2];
+  float dl[MAXQ], lse[MAXQ];
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    int qr = (wave + 4 * i) * 16 + fr;
+    qr = qr < L ? qr : L - 1;
     const size_t tok = (size_t)n * L + qr;
     const T* qp = base + (size_t)qr * ld + fg * 8;
-    const v8 q0 = *(const v8*)qp, q1 = *(const v8*)(qp + 32);
     const T* dop = (const T*)a.dout + tok * d + h * 64 + fg * 8;
     const T* op = (const T*)a.out + tok * d + h * 64 + fg * 8;
-    const v8 do0 = *(const v8*)dop, do1 = *(const v8*)(dop + 32);
+    qf[i][0] = *(const v8*)qp; qf[i][1] = *(const v8*)(qp + 32);
+    dof[i][0] = *(const v8*)dop; dof[i][1] = *(const v8*)(dop + 32);
     const v8 o0 = *(const v8*)op, o1 = *(const v8*)(op + 32);
-    float dl = 0.f;
+    float t = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dl += to_f32<T>(do0[e]) * to_f32<T>(o0[e]) + to_f32<T>(do1[e]) * to_f32<T>(o1[e]);
-    dl = quad_sum(dl);
-    const float lse = a.lse[((size_t)n * H + h) * L + qr];
-    if (qrow < L && fg == 0) a.delta[((size_t)n * H + h) * L + qrow] = dl;
+    for (int e = 0; e < 8; ++e) t += to_f32<T>(dof[i][0][e]) * to_f32<T>(o0[e]) + to_f32<T>(dof[i][1][e]) * to_f32<T>(o1[e]);
+    dl[i] = quad_sum(t);                                       // delta = rowsum(dO * O)
+    lse[i] = a.lse[((size_t)n * H + h) * L + qr];
+  }
+  stage_rows_dma<T>(sK, base + d, ld, L, LP, wave, lane);
+  stage_rows_dma<T>(sV, base + 2 * d, ld, L, LP, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+#pragma unroll
+  for (int qi = 0; qi < MAXQ; ++qi) {
+    const int qt = wave + 4 * qi;
+    if (qt >= nqt) break;
+    const int qrow = qt * 16 + fr;
+    if (qrow < L && fg == 0) a.delta[((size_t)n * H + h) * L + qrow] = dl[qi];
     const int nkt = CAUSAL ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;
     v8 dsf[NKT / 2];     // dS^T packed to 16-bit as soon as a 32-key block is done (register budget)
 #pragma unroll
@@ -266,16 +244,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
         dsv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (kt < nkt) {
           f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-          sv = mfma16<T>(frag_rows<T>(sK, kt, 0, fr, fg), q0, sv);
-          sv = mfma16<T>(frag_rows<T>(sK, kt, 1, fr, fg), q1, sv);
-          dp = mfma16<T>(frag_rows<T>(sV, kt, 0, fr, fg), do0, dp);
-          dp = mfma16<T>(frag_rows<T>(sV, kt, 1, fr, fg), do1, dp);
+          sv = mfma16<T>(frag_rows<T>(sK, kt, 0, fr, fg), qf[qi][0], sv);
+          sv = mfma16<T>(frag_rows<T>(sK, kt, 1, fr, fg), qf[qi][1], sv);
+          dp = mfma16<T>(frag_rows<T>(sV, kt, 0, fr, fg), dof[qi][0], dp);
+          dp = mfma16<T>(frag_rows<T>(sV, kt, 1, fr, fg), dof[qi][1], dp);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = kt * 16 + fg * 4 + r;
             const bool ok = key < L && (!CAUSAL || key <= qrow);
-            const float p = ok ? __expf(sv[r] * 0.125f - lse) : 0.f;
-            dsv[u][r] = p * (dp[r] - dl) * 0.125f;
+            const float p = ok ? __expf(sv[r] * 0.125f - lse[qi]) : 0.f;
+            dsv[u][r] = p * (dp[r] - dl[qi]) * 0.125f;
           }
         }
       }
@@ -288,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
     for (int kb = 0; kb < NKT / 2; ++kb) {
       if (2 * kb < nkt) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16<T>(frag_transposed<T>(sKt, VS, dt, kb, fr, fg), dsf[kb], dq[dt]);
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16<T>(frag_vt<T>(sK, kb, dt, fr, fg), dsf[kb], dq[dt]);
       }
     }
     if (qrow < L) {
@@ -307,43 +285,50 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
 // ======================================================================================= backward B: dK, dV
 // per key tile (col = key = lane&15), looping over 32-query blocks:
 //   S = Q K^T (rows = queries), P, dP = dO V^T, dS ;  dV^T += dO^T P ;  dK^T += Q^T dS.
-// LDS: Q rows, dO rows, Q transposed, dO transposed, lse[LP], delta[LP].
+// LDS: Q rows, dO rows (DMA-staged; Q^T / dO^T fragments by transpose-read), lse[LP], delta[LP].
 template <typename T, int NKT, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using v8 = typename Vec<T>::v8;
   using v4 = typename Vec<T>::v4;
-  constexpr int LP = NKT * 16, VS = LP + 8;
+  constexpr int LP = NKT * 16;
+  constexpr int MAXK = (NKT + 3) / 4;
   char* sQ = smem;
   char* sdO = smem + LP * 128;
-  T* sQt = (T*)(smem + 2 * LP * 128);
-  T* sdOt = sQt + 64 * VS;
-  float* sLse = (float*)(smem + 2 * LP * 128 + 2 * 64 * VS * 2);
+  float* sLse = (float*)(smem + 2 * LP * 128);
   float* sDel = sLse + LP;
   const int L = a.L, H = a.H, d = H * 64;
   const int n = blockIdx.x / H, h = blockIdx.x % H;
   const size_t ld = (size_t)3 * d;
   const T* base = (const T*)a.qkv + (size_t)n * L * ld + h * 64;
   const T* dob = (const T*)a.dout + (size_t)n * L * d + h * 64;
-  stage_rows<T>(sQ, base, ld, L, LP);
-  stage_rows<T>(sdO, dob, (size_t)d, L, LP);
-  stage_transposed<T>(sQt, base, ld, L, LP, VS);
-  stage_transposed<T>(sdOt, dob, (size_t)d, L, LP, VS);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nkt_all = (L + 15) >> 4;
+
+  v8 kf[MAXK][2], vf[MAXK][2];
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) {
+    int kr = (wave + 4 * i) * 16 + fr;
+    kr = kr < L ? kr : L - 1;
+    const T* kp = base + (size_t)kr * ld + d + fg * 8;
+    kf[i][0] = *(const v8*)kp; kf[i][1] = *(const v8*)(kp + 32);
+    vf[i][0] = *(const v8*)(kp + d); vf[i][1] = *(const v8*)(kp + d + 32);
+  }
   for (int i = threadIdx.x; i < LP; i += 256) {
     sLse[i] = i < L ? a.lse[((size_t)n * H + h) * L + i] : 0.f;
     sDel[i] = i < L ? a.delta[((size_t)n * H + h) * L + i] : 0.f;
   }
+  stage_rows_dma<T>(sQ, base, ld, L, LP, wave, lane);
+  stage_rows_dma<T>(sdO, dob, (size_t)d, L, LP, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int fr = lane & 15, fg = lane >> 4;
-  const int nkt_all = (L + 15) >> 4;
-  for (int kt = wave; kt < nkt_all; kt += 4) {
+#pragma unroll
+  for (int ki = 0; ki < MAXK; ++ki) {
+    const int kt = wave + 4 * ki;
+    if (kt >= nkt_all) break;
     const int key = kt * 16 + fr;
-    const int kr = key < L ? key : L - 1;
-    const T* kp = base + (size_t)kr * ld + d + fg * 8;
-    const v8 k0 = *(const v8*)kp, k1 = *(const v8*)(kp + 32);
-    const v8 v0 = *(const v8*)(kp + d), v1 = *(const v8*)(kp + d + 32);
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -356,10 +341,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
         for (int u = 0; u < 2; ++u) {
           const int qt = 2 * qb + u;
           f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-          sv = mfma16<T>(frag_rows<T>(sQ, qt, 0, fr, fg), k0, sv);
-          sv = mfma16<T>(frag_rows<T>(sQ, qt, 1, fr, fg), k1, sv);
-          dp = mfma16<T>(frag_rows<T>(sdO, qt, 0, fr, fg), v0, dp);
-          dp = mfma16<T>(frag_rows<T>(sdO, qt, 1, fr, fg), v1, dp);
+          sv = mfma16<T>(frag_rows<T>(sQ, qt, 0, fr, fg), kf[ki][0], sv);
+          sv = mfma16<T>(frag_rows<T>(sQ, qt, 1, fr, fg), kf[ki][1], sv);
+          dp = mfma16<T>(frag_rows<T>(sdO, qt, 0, fr, fg), vf[ki][0], dp);
+          dp = mfma16<T>(frag_rows<T>(sdO, qt, 1, fr, fg), vf[ki][1], dp);
           const f32x4 l4 = *(const f32x4*)(sLse + qt * 16 + fg * 4);
           const f32x4 d4 = *(const f32x4*)(sDel + qt * 16 + fg * 4);
 #pragma unroll
@@ -375,8 +360,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
         const v8 dsf = pack8<T>(ds[0], ds[1]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          dv[dt] = mfma16<T>(frag_transposed<T>(sdOt, VS, dt, qb, fr, fg), pf, dv[dt]);
-          dk[dt] = mfma16<T>(frag_transposed<T>(sQt, VS, dt, qb, fr, fg), dsf, dk[dt]);
+          dv[dt] = mfma16<T>(frag_vt<T>(sdO, qb, dt, fr, fg), pf, dv[dt]);
+          dk[dt] = mfma16<T>(frag_vt<T>(sQ, qb, dt, fr, fg), dsf, dk[dt]);
         }
       }
     }
@@ -406,9 +391,9 @@ static hipError_t fwd_t(const AttnArgs& a, hipStream_t s) {
 }
 template <typename T, int NKT, bool CAUSAL>
 static hipError_t bwd_t(const AttnBwdArgs& a, hipStream_t s) {
-  constexpr int LP = NKT * 16, VS = LP + 8;
-  constexpr int lds_a = 2 * LP * 128 + 64 * VS * 2;
-  constexpr int lds_b = 2 * LP * 128 + 2 * 64 * VS * 2 + 2 * LP * 4;
+  constexpr int LP = NKT * 16;
+  constexpr int lds_a = 2 * LP * 128;
+  constexpr int lds_b = 2 * LP * 128 + 2 * LP * 4;
   static bool set = false;
   if (!set) {
     hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, NKT, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);

@@ -306,13 +306,26 @@ class _PromptedClipFn(torch.autograd.Function):
         # (grad mode is off inside Function.forward: ask autograd which inputs need a gradient)
         need_txt = bool(fctx.needs_input_grad[4])
         need_img = bool(fctx.needs_input_grad[5] or fctx.needs_input_grad[6])
-        img = eng.image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
-        if coop_emb is None and model._const_text_features is not None:
-            txt = model._const_text_features
+        run_text = not (coop_emb is None and model._const_text_features is not None)
+        side = model._side_stream if (run_text and model.overlap_towers) else None
+        if side is not None:
+            # The two towers are independent until the logits: the text tower (few, small launches that cannot
+            # fill 256 CUs) runs on a second HIP stream underneath the image tower's large GEMMs.
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                txt = eng.text_fwd(pl.token_prefix, pl.token_suffix, coop_emb, pl.layout, pl.eot, save_for_bwd=need_txt)
+            img = eng.image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
+            main.wait_stream(side)
+            txt.record_stream(main)
         else:
-            txt = eng.text_fwd(pl.token_prefix, pl.token_suffix, coop_emb, pl.layout, pl.eot, save_for_bwd=need_txt)
-            if coop_emb is None:
-                model._const_text_features = txt     # no text context: features are constants
+            img = eng.image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
+            if run_text:
+                txt = eng.text_fwd(pl.token_prefix, pl.token_suffix, coop_emb, pl.layout, pl.eot, save_for_bwd=need_txt)
+        if not run_text:
+            txt = model._const_text_features
+        elif coop_emb is None:
+            model._const_text_features = txt     # no text context: features are constants
         logits = eng.logits_fwd(img, txt, model.logit_scale_exp, task_lo, task_hi)
         fctx.model, fctx.need_img, fctx.need_txt = model, need_img, need_txt
         fctx.has_deep = vpt_deep_emb is not None
@@ -363,6 +376,8 @@ class CustomCLIP(nn.Module):
         self.dtype = clip_model.dtype
         self._const_text_features = None
         self.last_ncorrect = None
+        self.overlap_towers = True
+        self._side_stream = torch.cuda.Stream(device=clip_model.device) if torch.cuda.is_available() else None
         self.multi_task_label_pertask = cfg.DATASET.MULTITASK_LABEL_PERTASK
         if self.multi_task_label_pertask:
             # indexed by task id; sized num_classes as in the reference (:529-537)
