@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const T* base = (const T*)a.qkv + (size_t)n * L * ld + h * 64;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int nqt = (L + 15) >> 4;
+  const int nqt = a.q_rows > 0 ? ((a.q_rows < L ? a.q_rows : L) + 15) >> 4 : (L + 15) >> 4;
   // every Q fragment this wave will need is requested before the K/V DMA is waited for (one latency, not one per tile)
   constexpr int MAXQ = (NKT + 3) / 4;
   v8 qf[MAXQ][2];

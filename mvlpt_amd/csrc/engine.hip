@@ -87,6 +87,7 @@ struct Engine {
   TowerState vs, ts;
   // vision fwd extras (carved from vis_ws)
   int vB = 0, v_nvpt = 0, v_ndeep = 0; float* cls32 = nullptr; float* dcls32 = nullptr;
+  float* xc32 = nullptr; void *ac16 = nullptr, *hc16 = nullptr, *gc16 = nullptr;   // CLS-only last layer (compact [B,·])
   // text fwd extras
   int tC = 0, tL = 0, t_nctx = 0, t_per_class = 0; int32_t* eot_rows = nullptr; int32_t* ctx_pos = nullptr;
   float* eot32 = nullptr; float* deot32 = nullptr;
@@ -451,7 +452,7 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   const bool save = save_for_bwd != 0;
   const size_t npatch = (size_t)B * G2;
   size_t need = tower_bytes(E->vis, B, Lv, save) + align256(npatch * E->Kp * 2) + align256(npatch * dv * 4) +
-                2 * align256((size_t)B * dv * 4) + 4096;
+                3 * align256((size_t)B * dv * 4) + 2 * align256((size_t)B * dv * 2) + align256((size_t)B * dv * 8) + 4096;
   E->vs.valid = false;
   HIPCHK(E, E->vis_ws.reserve(need));
   Bump bp; bp.base = (char*)E->vis_ws.p; bp.cap = E->vis_ws.cap;
@@ -459,6 +460,9 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   float* pe = bp.take<float>(npatch * dv);
   E->cls32 = bp.take<float>((size_t)B * dv);
   E->dcls32 = bp.take<float>((size_t)B * dv);
+  E->xc32 = bp.take<float>((size_t)B * dv);
+  E->ac16 = bp.take_bytes((size_t)B * dv * 2); E->hc16 = bp.take_bytes((size_t)B * dv * 2);
+  E->gc16 = bp.take_bytes((size_t)B * dv * 4 * 2);
   carve_tower(bp, E->vis, E->vs, B, Lv, save, false);
   TowerState& st = E->vs;
   E->vB = B; E->v_nvpt = n_vpt; E->v_ndeep = n_deep;
@@ -468,6 +472,7 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   HIPCHK(E, gemm(E, EPI_STORE32, patches, E->conv_w, (int)npatch, dv, E->Kp, nullptr, nullptr, nullptr, pe, nullptr, s));
   { ProfScope ps(E, s, PC_GLUE, 0, (double)B * Lv * dv * 8.0);
     HIPCHK(E, launch_assemble_tokens(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, vpt, n_vpt, st.x[0], B, G2, dv, s)); }
+  bool cls_only_last = false;
   for (int l = 0; l < E->vis.layers; ++l) {
     if (l > 0 && n_deep > 0) {
       if (l <= n_deep) {
@@ -482,8 +487,33 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
         continue;
       }
     }
+    if (l == E->vis.layers - 1 && !save) { cls_only_last = true; break; }
     if (int rc = block_fwd(E, E->vis, st, l, s)) return rc;
   }
+  if (cls_only_last) {
+    // Only x[:, 0, :] of the last block is consumed (trainers/mvlpt.py:88) and, with no backward to feed, nothing
+    // else of it is observable: keys/values are still needed for every token, but queries, out-proj, ln_2 and the
+    // MLP are evaluated for the CLS row only (B rows instead of B*Lv: ~20/24 of the layer's GEMM FLOPs vanish).
+    const int l = E->vis.layers - 1;
+    const Block& Bk = E->vis.blocks[l];
+    const int T = B * Lv;
+    float* xin = st.x[2 * l];
+    HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dv, s));
+    HIPCHK(E, gemm(E, EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dv, dv, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s));
+    {
+      AttnArgs a{st.qkv[l], st.attn[l], nullptr, st.N, st.L, st.H, 0, 1};
+      ProfScope ps(E, s, PC_ATTN_FWD, 4.0 * st.L * 64.0 * st.N * st.H, (double)T * dv * 2.0 * 2.0);
+      HIPCHK(E, launch_attn_fwd(E->dt, a, s));
+    }
+    { ProfScope ps(E, s, PC_GLUE, 0, (double)B * dv * 12.0);
+      HIPCHK(E, hipMemcpy2DAsync(E->ac16, (size_t)dv * 2, st.attn[l], (size_t)Lv * dv * 2, (size_t)dv * 2, B, hipMemcpyDeviceToDevice, s));
+      HIPCHK(E, hipMemcpy2DAsync(E->xc32, (size_t)dv * 4, xin, (size_t)Lv * dv * 4, (size_t)dv * 4, B, hipMemcpyDeviceToDevice, s)); }
+    HIPCHK(E, gemm(E, EPI_RESID32, E->ac16, Bk.o.w, B, dv, dv, Bk.o.b, nullptr, E->xc32, E->xc32, nullptr, s));
+    HIPCHK(E, ln_fwd(E, E->dt, E->xc32, nullptr, 1, Bk.ln2, E->hc16, B, dv, s));
+    HIPCHK(E, gemm(E, EPI_GELU, E->hc16, Bk.fc.w, B, 4 * dv, dv, Bk.fc.b, nullptr, nullptr, E->gc16, nullptr, s));
+    HIPCHK(E, gemm(E, EPI_RESID32, E->gc16, Bk.pr.w, B, dv, 4 * dv, Bk.pr.b, nullptr, E->xc32, E->xc32, nullptr, s));
+    HIPCHK(E, ln_fwd(E, DT_F32, E->xc32, nullptr, 1, E->ln_post, E->cls32, B, dv, s));
+  } else
   // ln_post on the CLS row, then @ proj   (trainers/mvlpt.py:88-91)
   HIPCHK(E, ln_fwd(E, DT_F32, st.x[2 * E->vis.layers], nullptr, Lv, E->ln_post, E->cls32, B, dv, s));
   { ProfScope ps(E, s, PC_HEAD, 2.0 * B * e * dv, 4.0 * ((double)B * dv + (double)e * dv + (double)B * e));

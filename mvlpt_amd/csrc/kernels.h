@@ -59,6 +59,7 @@ hipError_t launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s);
 struct AttnArgs {
   const void* qkv; void* out /*[N*L,d]*/; float* lse /*[N*H*L] or null*/;
   int N, L, H; int causal;
+  int q_rows = 0;   // > 0: only queries 0..q_rows-1 of every sequence are computed (last layer: only CLS is consumed)
 };
 hipError_t launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s);
 struct AttnBwdArgs {
