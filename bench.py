@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak of one MI355X (MI355X_MICROARCH.md)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "gemm_hbm_traffic.json")   # written from rocprofv3 --pmc passes
 
 
 def algorithmic_gflop_per_image(arch, B_global, C, L_text, n_ctx, n_vpt, causal_half=True):
@@ -183,20 +184,27 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: MVLPT {args.method} head, {args.arch}, {args.classes} classes, "
-                                   f"n_ctx={n_ctx} n_vpt={n_vpt}, text L={L_text}, class token middle",
+            "config": {"workload": (("BASELINE configs[1]: " if (args.method, args.arch, args.classes, args.batch) ==
+                                     ("coop", "ViT-B/16", 100, 256) else "variant: ") +
+                                    f"MVLPT {args.method} head, {args.arch}, {args.classes} classes, "
+                                    f"n_ctx={n_ctx} n_vpt={n_vpt}, text L={L_text}, class token middle"),
                        "per_gpu_batch": args.batch, "global_batch": B_global, "parallelism": f"dp{world}",
                        "text_tower": "replicated per GPU", "loss": round(loss, 5)},
             "step_mfma_fraction": round(ips / world * gf_img / (MFMA_PEAK_TFLOPS * 1e3), 4),
             "algorithmic_gflop_per_image": round(gf_img, 3),
         }
+        traffic = None
+        if os.path.isfile(TRAFFIC_FILE) and args.method == "coop" and args.batch == 256:
+            with open(TRAFFIC_FILE) as f:
+                traffic = json.load(f)       # {"bytes_per_launch": …, "source": "rocprofv3 --pmc …"} (offline PMC passes)
         if "gemm_bt" in stats:
             g = stats["gemm_bt"]
             tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_bt_kernel (all epilogues)", "achieved": round(tf, 1),
                                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
-                                "traffic": None, "launches_per_step": g["launches"] // args.steps,
+                                "traffic": traffic, "launches_per_step": g["launches"] // args.steps,
                                 "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
+                                "algorithmic_bytes_per_launch": int(g["bytes"] / g["launches"]),
                                 "share_of_step_time": round(g["ms"] / (1e3 * elapsed), 3),
                                 "concurrency": "text tower on a 2nd stream overlaps the image tower in the timed region"}
             if "gemm_bt" in stats_serial:
