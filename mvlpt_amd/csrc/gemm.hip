@@ -76,7 +76,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
           const int r = it * 8 + (lane >> 3), c = lane & 7;   // 8 lanes x 16 B = one 128-B row segment
           const v8 w = *(const v8*)(scratch + r * RS + c * 16);
           const int m = mbase + half * 32 + r;
-          if (m < M) *(v8*)(outp + (size_t)m * N + nbase + c * 8) = w;
+          if (m < M) __builtin_nontemporal_store(w, (v8*)(outp + (size_t)m * N + nbase + c * 8));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // scratch is rewritten by the next pass
       }
@@ -95,8 +95,8 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
         for (int it = 0; it < 4; ++it) {
           int m = mbase + i * 16 + it * 4 + rq;
           m = m < M ? m : M - 1;
-          if constexpr (EPI == EPI_RESID32) rv[i][it] = *(const f32x4*)(g.resid + (size_t)m * N + nbase + c * 4);
-          else uv[i][it] = *(const v4*)((const T*)g.aux + (size_t)m * N + nbase + c * 4);
+          if constexpr (EPI == EPI_RESID32) rv[i][it] = __builtin_nontemporal_load((const f32x4*)(g.resid + (size_t)m * N + nbase + c * 4));
+          else uv[i][it] = __builtin_nontemporal_load((const v4*)((const T*)g.aux + (size_t)m * N + nbase + c * 4));
         }
     }
 #pragma unroll
@@ -112,14 +112,14 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
         const size_t o = (size_t)m * N + nbase + c * 4;
         if constexpr (EPI == EPI_RESID32) {
           v += rv[i][it];
-          if (m < M) *(f32x4*)((float*)g.out + o) = v;
+          if (m < M) __builtin_nontemporal_store(v, (f32x4*)((float*)g.out + o));
         } else if constexpr (EPI == EPI_GELUBWD) {
           v4 w;
 #pragma unroll
           for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(v[e] * quick_gelu_grad(to_f32<T>(uv[i][it][e])));
-          if (m < M) *(v4*)((T*)g.out + o) = w;
+          if (m < M) __builtin_nontemporal_store(w, (v4*)((T*)g.out + o));
         } else {  // EPI_STORE32
-          if (m < M) *(f32x4*)((float*)g.out + o) = v;
+          if (m < M) __builtin_nontemporal_store(v, (f32x4*)((float*)g.out + o));
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -151,6 +151,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void gemm_bt_kernel(GemmA
   const int ntiles = ((M + BM_ - 1) / BM_) * tilesN;
   const int gq = G >> 3, gr = G & 7, xcd = b & 7;
   const int b_remap = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (b >> 3);
+  // Tile enumeration: N-fastest (the tiles an XCD runs concurrently share 1-2 A panels).  A grouped, weight-resident
+  // enumeration was measured and was not faster (A panels are then re-read from the Infinity Cache once per group).
+  auto tile_mn = [&](int t, int& tm, int& tn) { tm = t / tilesN; tn = t - tm * tilesN; };
   auto tile_of = [&](int round) -> int {
     const int base = round * G;
     return base + ((base + G <= ntiles) ? b_remap : b);   // ragged last round: plain order keeps XCDs balanced
@@ -163,7 +166,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void gemm_bt_kernel(GemmA
   const T* ap[A_IT];
   const T* bp[B_IT];
   auto set_ptrs = [&](int t) {
-    const int m0 = (t / tilesN) * BM_, n0 = (t % tilesN) * BN;
+    int tm, tn;
+    tile_mn(t, tm, tn);
+    const int m0 = tm * BM_, n0 = tn * BN;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       int ar = m0 + (i * NW + wave) * 8 + srow; ar = ar < M ? ar : M - 1;   // edge rows are re-read, never stored
@@ -257,7 +262,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void gemm_bt_kernel(GemmA
     }
     // the slot the load cursor will fill next has just been released by the barrier above: use it as scratch,
     // and fence the scratch reads of all waves against that DMA with one more barrier
-    epilogue_store<T, EPI>(g, acc, (t / tilesN) * BM_ + wm * 64, (t % tilesN) * BN + wn * 64, lane,
+    int tm, tn;
+    tile_mn(t, tm, tn);
+    epilogue_store<T, EPI>(g, acc, tm * BM_ + wm * 64, tn * BN + wn * 64, lane,
                            smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE);
     __builtin_amdgcn_s_barrier();
   }
