@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--method", default="coop", choices=["coop", "vpt", "upt"])
     ap.add_argument("--cut", action="store_true", help="CUT_CONTEXTLEN text length instead of 77")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--shard-text", action="store_true", help="class-shard the text tower over the ranks (many-class configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--all-kernel-timing", action="store_true", help="bracket every kernel class with marker events (slower)")
@@ -133,6 +134,8 @@ def main():
     dm = SyntheticDataManager(cfg, args.classes, n_batches, device=dev, seed=1234 + rank)
     trainer = MVLPT(cfg, dm=dm, clip_state_dict=sd)
     trainer.num_batches = 10 ** 9   # no LR-schedule step inside the timed region
+    if args.shard_text and world > 1:
+        trainer.model.enable_class_sharding(rank, world)
     L_text = trainer.model.prompt_learner.tokenized_prompts.shape[1]
     eng = trainer.model.engine
 
@@ -189,7 +192,7 @@ def main():
                                     f"MVLPT {args.method} head, {args.arch}, {args.classes} classes, "
                                     f"n_ctx={n_ctx} n_vpt={n_vpt}, text L={L_text}, class token middle"),
                        "per_gpu_batch": args.batch, "global_batch": B_global, "parallelism": f"dp{world}",
-                       "text_tower": "replicated per GPU", "loss": round(loss, 5)},
+                       "text_tower": "class-sharded over ranks" if (args.shard_text and world > 1) else "replicated per GPU", "loss": round(loss, 5)},
             "step_mfma_fraction": round(ips / world * gf_img / (MFMA_PEAK_TFLOPS * 1e3), 4),
             "algorithmic_gflop_per_image": round(gf_img, 3),
         }

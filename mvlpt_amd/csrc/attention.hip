@@ -19,7 +19,7 @@
 
 namespace mvlpt {
 
-constexpr int ATT_MAX_NKT = 16;  // 16 tiles * 16 keys = 256
+constexpr int ATT_MAX_NKT = 38;  // 38 tiles * 16 keys = 608: ViT-L/14@336 (577 + prompts); K+V images fill 152 of 160 KiB LDS
 int attn_max_len() { return ATT_MAX_NKT * 16; }
 
 // ---- staging helpers -------------------------------------------------------------------------------------
@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   using v8 = typename Vec<T>::v8;
   using v4 = typename Vec<T>::v4;
   constexpr int LP = NKT * 16;
+  constexpr int BLK = NKT < 16 ? NKT : 16;      // key tiles per softmax block (online softmax across blocks, L > 256)
+  constexpr bool PRELOAD = NKT <= 16;
   char* sK = smem;                            // [LP][64] row-major, 16-B chunks swizzled by (row & 7)
   char* sV = smem + LP * 128;                 // same image for V; transposed on the fly by ds_read_b64_tr_b16
   const int L = a.L, H = a.H, d = H * 64;
@@ -104,16 +106,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const int nqt = a.q_rows > 0 ? ((a.q_rows < L ? a.q_rows : L) + 15) >> 4 : (L + 15) >> 4;
-  // every Q fragment this wave will need is requested before the K/V DMA is waited for (one latency, not one per tile)
-  constexpr int MAXQ = (NKT + 3) / 4;
+  // short sequences: every Q fragment this wave will need is requested before the K/V DMA is waited for
+  constexpr int MAXQ = PRELOAD ? (NKT + 3) / 4 : 1;
   v8 qf[MAXQ][2];
+  if constexpr (PRELOAD) {
 #pragma unroll
-  for (int i = 0; i < MAXQ; ++i) {
-    int qr = (wave + 4 * i) * 16 + fr;
-    qr = qr < L ? qr : L - 1;
-    const T* qp = base + (size_t)qr * ld + fg * 8;
-    qf[i][0] = *(const v8*)qp;
-    qf[i][1] = *(const v8*)(qp + 32);
+    for (int i = 0; i < MAXQ; ++i) {
+      int qr = (wave + 4 * i) * 16 + fr;
+      qr = qr < L ? qr : L - 1;
+      const T* qp = base + (size_t)qr * ld + fg * 8;
+      qf[i][0] = *(const v8*)qp;
+      qf[i][1] = *(const v8*)(qp + 32);
+    }
   }
   stage_rows_dma<T>(sK, base + d, ld, L, LP, wave, lane);
   stage_rows_dma<T>(sV, base + 2 * d, ld, L, LP, wave, lane);
@@ -121,52 +125,59 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   __syncthreads();
 
   constexpr float SC = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e): softmax in base 2
-#pragma unroll
-  for (int qi = 0; qi < MAXQ; ++qi) {
-    const int qt = wave + 4 * qi;
-    if (qt >= nqt) break;
+  auto process = [&](const int qt, const v8 q0, const v8 q1) {
     const int qrow = qt * 16 + fr;
-    const v8 q0 = qf[qi][0], q1 = qf[qi][1];
     const int nkt = CAUSAL ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;   // key tiles that can be unmasked
-    f32x4 s[NKT];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kt < nkt) {
-        s[kt] = mfma16<T>(frag_rows<T>(sK, kt, 0, fr, fg), q0, s[kt]);
-        s[kt] = mfma16<T>(frag_rows<T>(sK, kt, 1, fr, fg), q1, s[kt]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + fg * 4 + r;
-          const bool ok = key < L && (!CAUSAL || key <= qrow);
-          s[kt][r] = ok ? s[kt][r] * SC : -INFINITY;
-          mx = fmaxf(mx, s[kt][r]);
-        }
-      }
-    }
-    mx = quad_max(mx);          // finite: key 0 is always unmasked
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (kt < nkt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx); sum += s[kt][r]; }
-      }
-    }
-    sum = quad_sum(sum);
-    const float inv = 1.0f / sum;
+    float mrun = -INFINITY, sum = 0.f;
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < NKT / 2; ++kb) {
-      if (2 * kb < nkt) {
-        const v8 pf = pack8<T>(s[2 * kb], s[2 * kb + 1]);
+    for (int k0 = 0; k0 < NKT; k0 += BLK) {
+      if (k0 >= nkt) break;
+      f32x4 s[BLK];
+      float mx = -INFINITY;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16<T>(frag_vt<T>(sV, kb, dt, fr, fg), pf, o[dt]);
+      for (int u = 0; u < BLK; ++u) {
+        const int kt = k0 + u;
+        s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kt < NKT && kt < nkt) {
+          s[u] = mfma16<T>(frag_rows<T>(sK, kt, 0, fr, fg), q0, s[u]);
+          s[u] = mfma16<T>(frag_rows<T>(sK, kt, 1, fr, fg), q1, s[u]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + fg * 4 + r;
+            const bool ok = key < L && (!CAUSAL || key <= qrow);
+            s[u][r] = ok ? s[u][r] * SC : -INFINITY;
+            mx = fmaxf(mx, s[u][r]);
+          }
+        }
+      }
+      mx = quad_max(mx);
+      const float mnew = fmaxf(mrun, mx);           // finite from the first block on: key 0 is never masked
+      const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);   // first block: exp2(-inf) = 0 on zero accumulators
+      mrun = mnew;
+      sum *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+#pragma unroll
+      for (int u = 0; u < BLK; ++u) {
+        if (k0 + u < NKT && k0 + u < nkt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s[u][r] = __builtin_amdgcn_exp2f(s[u][r] - mnew); sum += s[u][r]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BLK; u += 2) {
+        if (k0 + u < NKT && k0 + u < nkt) {
+          const v8 pf = pack8<T>(s[u], s[u + 1]);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16<T>(frag_vt<T>(sV, (k0 + u) >> 1, dt, fr, fg), pf, o[dt]);
+        }
       }
     }
+    sum = quad_sum(sum);
+    const float inv = 1.0f / sum;
     if (qrow < L) {
       T* op = (T*)a.out + ((size_t)n * L + qrow) * d + h * 64 + fg * 4;
 #pragma unroll
@@ -177,7 +188,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         *(v4*)(op + dt * 16) = w;
       }
       // natural-log LSE of the scaled scores (the backward recomputes P = exp(s/8 - lse))
-      if (a.lse && fg == 0) a.lse[((size_t)n * H + h) * L + qrow] = (mx + log2f(sum)) * 0.6931471805599453f;
+      if (a.lse && fg == 0) a.lse[((size_t)n * H + h) * L + qrow] = (mrun + log2f(sum)) * 0.6931471805599453f;
+    }
+  };
+  if constexpr (PRELOAD) {
+#pragma unroll
+    for (int qi = 0; qi < MAXQ; ++qi) {
+      if (wave + 4 * qi >= nqt) break;
+      process(wave + 4 * qi, qf[qi][0], qf[qi][1]);
+    }
+  } else {
+    for (int qt = wave; qt < nqt; qt += 4) {
+      const int qrow = qt * 16 + fr;
+      const T* qp = base + (size_t)(qrow < L ? qrow : L - 1) * ld + fg * 8;
+      process(qt, *(const v8*)qp, *(const v8*)(qp + 32));
     }
   }
 }
@@ -192,6 +216,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
   using v4 = typename Vec<T>::v4;
   constexpr int LP = NKT * 16;
   constexpr int MAXQ = (NKT + 3) / 4;
+  constexpr int DSB = NKT > 16 ? 4 : (NKT / 2 < 8 ? NKT / 2 : 8);   // 32-key blocks of dS^T held at a time (register budget)
   char* sK = smem;
   char* sV = smem + LP * 128;
   const int L = a.L, H = a.H, d = H * 64;
@@ -202,71 +227,80 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
   const int fr = lane & 15, fg = lane >> 4;
   const int nqt = (L + 15) >> 4;
 
-  // per-wave operands straight from global, requested before the K/V DMA is waited for
-  v8 qf[MAXQ][2], dof[MAXQ][2];
-  float dl[MAXQ], lse[MAXQ];
-#pragma unroll
-  for (int i = 0; i < MAXQ; ++i) {
-    int qr = (wave + 4 * i) * 16 + fr;
+  // per-wave operands straight from global; short sequences request all of them before the K/V DMA is waited for
+  struct QOps { v8 q0, q1, do0, do1; float dl, lse; };
+  auto load_ops = [&](int qt) -> QOps {
+    QOps r;
+    int qr = qt * 16 + fr;
     qr = qr < L ? qr : L - 1;
     const size_t tok = (size_t)n * L + qr;
     const T* qp = base + (size_t)qr * ld + fg * 8;
     const T* dop = (const T*)a.dout + tok * d + h * 64 + fg * 8;
     const T* op = (const T*)a.out + tok * d + h * 64 + fg * 8;
-    qf[i][0] = *(const v8*)qp; qf[i][1] = *(const v8*)(qp + 32);
-    dof[i][0] = *(const v8*)dop; dof[i][1] = *(const v8*)(dop + 32);
+    r.q0 = *(const v8*)qp; r.q1 = *(const v8*)(qp + 32);
+    r.do0 = *(const v8*)dop; r.do1 = *(const v8*)(dop + 32);
     const v8 o0 = *(const v8*)op, o1 = *(const v8*)(op + 32);
     float t = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) t += to_f32<T>(dof[i][0][e]) * to_f32<T>(o0[e]) + to_f32<T>(dof[i][1][e]) * to_f32<T>(o1[e]);
-    dl[i] = quad_sum(t);                                       // delta = rowsum(dO * O)
-    lse[i] = a.lse[((size_t)n * H + h) * L + qr];
+    for (int e = 0; e < 8; ++e) t += to_f32<T>(r.do0[e]) * to_f32<T>(o0[e]) + to_f32<T>(r.do1[e]) * to_f32<T>(o1[e]);
+    r.dl = quad_sum(t);                                        // delta = rowsum(dO * O)
+    r.lse = a.lse[((size_t)n * H + h) * L + qr];
+    return r;
+  };
+  constexpr bool PRELOAD = NKT <= 16;
+  QOps pre[PRELOAD ? MAXQ : 1];
+  if constexpr (PRELOAD) {
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) pre[i] = load_ops(wave + 4 * i);
   }
   stage_rows_dma<T>(sK, base + d, ld, L, LP, wave, lane);
   stage_rows_dma<T>(sV, base + 2 * d, ld, L, LP, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-#pragma unroll
-  for (int qi = 0; qi < MAXQ; ++qi) {
-    const int qt = wave + 4 * qi;
-    if (qt >= nqt) break;
+  auto process = [&](const int qt, const QOps& O_) {
     const int qrow = qt * 16 + fr;
-    if (qrow < L && fg == 0) a.delta[((size_t)n * H + h) * L + qrow] = dl[qi];
+    if (qrow < L && fg == 0) a.delta[((size_t)n * H + h) * L + qrow] = O_.dl;
     const int nkt = CAUSAL ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;
-    v8 dsf[NKT / 2];     // dS^T packed to 16-bit as soon as a 32-key block is done (register budget)
-#pragma unroll
-    for (int kb = 0; kb < NKT / 2; ++kb) {
-      f32x4 dsv[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int kt = 2 * kb + u;
-        dsv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (kt < nkt) {
-          f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-          sv = mfma16<T>(frag_rows<T>(sK, kt, 0, fr, fg), qf[qi][0], sv);
-          sv = mfma16<T>(frag_rows<T>(sK, kt, 1, fr, fg), qf[qi][1], sv);
-          dp = mfma16<T>(frag_rows<T>(sV, kt, 0, fr, fg), dof[qi][0], dp);
-          dp = mfma16<T>(frag_rows<T>(sV, kt, 1, fr, fg), dof[qi][1], dp);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kt * 16 + fg * 4 + r;
-            const bool ok = key < L && (!CAUSAL || key <= qrow);
-            const float p = ok ? __expf(sv[r] * 0.125f - lse[qi]) : 0.f;
-            dsv[u][r] = p * (dp[r] - dl[qi]) * 0.125f;
-          }
-        }
-      }
-      dsf[kb] = pack8<T>(dsv[0], dsv[1]);
-    }
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < NKT / 2; ++kb) {
-      if (2 * kb < nkt) {
+    for (int kb0 = 0; kb0 < NKT / 2; kb0 += DSB) {
+      if (2 * kb0 >= nkt) break;
+      v8 dsf[DSB];     // dS^T packed to 16-bit as soon as a 32-key block is done
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16<T>(frag_vt<T>(sK, kb, dt, fr, fg), dsf[kb], dq[dt]);
+      for (int w = 0; w < DSB; ++w) {
+        const int kb = kb0 + w;
+        f32x4 dsv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int kt = 2 * kb + u;
+          dsv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (kt < NKT && kt < nkt) {
+            f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+            sv = mfma16<T>(frag_rows<T>(sK, kt, 0, fr, fg), O_.q0, sv);
+            sv = mfma16<T>(frag_rows<T>(sK, kt, 1, fr, fg), O_.q1, sv);
+            dp = mfma16<T>(frag_rows<T>(sV, kt, 0, fr, fg), O_.do0, dp);
+            dp = mfma16<T>(frag_rows<T>(sV, kt, 1, fr, fg), O_.do1, dp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = kt * 16 + fg * 4 + r;
+              const bool ok = key < L && (!CAUSAL || key <= qrow);
+              const float p = ok ? __expf(sv[r] * 0.125f - O_.lse) : 0.f;
+              dsv[u][r] = p * (dp[r] - O_.dl) * 0.125f;
+            }
+          }
+        }
+        dsf[w] = pack8<T>(dsv[0], dsv[1]);
+      }
+#pragma unroll
+      for (int w = 0; w < DSB; ++w) {
+        const int kb = kb0 + w;
+        if (2 * kb < NKT && 2 * kb < nkt) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16<T>(frag_vt<T>(sK, kb, dt, fr, fg), dsf[w], dq[dt]);
+        }
       }
     }
     if (qrow < L) {
@@ -279,6 +313,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
         *(v4*)(gp + dt * 16) = w;
       }
     }
+  };
+  if constexpr (PRELOAD) {
+#pragma unroll
+    for (int qi = 0; qi < MAXQ; ++qi) {
+      if (wave + 4 * qi >= nqt) break;
+      process(wave + 4 * qi, pre[qi]);
+    }
+  } else {
+    for (int qt = wave; qt < nqt; qt += 4) process(qt, load_ops(qt));
   }
 }
 
@@ -306,14 +349,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
   const int fr = lane & 15, fg = lane >> 4;
   const int nkt_all = (L + 15) >> 4;
 
-  v8 kf[MAXK][2], vf[MAXK][2];
-#pragma unroll
-  for (int i = 0; i < MAXK; ++i) {
-    int kr = (wave + 4 * i) * 16 + fr;
+  struct KOps { v8 k0, k1, v0, v1; };
+  auto load_kv = [&](int kt) -> KOps {
+    KOps r;
+    int kr = kt * 16 + fr;
     kr = kr < L ? kr : L - 1;
     const T* kp = base + (size_t)kr * ld + d + fg * 8;
-    kf[i][0] = *(const v8*)kp; kf[i][1] = *(const v8*)(kp + 32);
-    vf[i][0] = *(const v8*)(kp + d); vf[i][1] = *(const v8*)(kp + d + 32);
+    r.k0 = *(const v8*)kp; r.k1 = *(const v8*)(kp + 32);
+    r.v0 = *(const v8*)(kp + d); r.v1 = *(const v8*)(kp + d + 32);
+    return r;
+  };
+  constexpr bool PRELOAD = NKT <= 16;
+  KOps pre[PRELOAD ? MAXK : 1];
+  if constexpr (PRELOAD) {
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) pre[i] = load_kv(wave + 4 * i);
   }
   for (int i = threadIdx.x; i < LP; i += 256) {
     sLse[i] = i < L ? a.lse[((size_t)n * H + h) * L + i] : 0.f;
@@ -324,10 +374,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-#pragma unroll
-  for (int ki = 0; ki < MAXK; ++ki) {
-    const int kt = wave + 4 * ki;
-    if (kt >= nkt_all) break;
+  auto process = [&](const int kt, const KOps& K_) {
     const int key = kt * 16 + fr;
     f32x4 dk[4], dv[4];
 #pragma unroll
@@ -341,10 +388,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
         for (int u = 0; u < 2; ++u) {
           const int qt = 2 * qb + u;
           f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-          sv = mfma16<T>(frag_rows<T>(sQ, qt, 0, fr, fg), kf[ki][0], sv);
-          sv = mfma16<T>(frag_rows<T>(sQ, qt, 1, fr, fg), kf[ki][1], sv);
-          dp = mfma16<T>(frag_rows<T>(sdO, qt, 0, fr, fg), vf[ki][0], dp);
-          dp = mfma16<T>(frag_rows<T>(sdO, qt, 1, fr, fg), vf[ki][1], dp);
+          sv = mfma16<T>(frag_rows<T>(sQ, qt, 0, fr, fg), K_.k0, sv);
+          sv = mfma16<T>(frag_rows<T>(sQ, qt, 1, fr, fg), K_.k1, sv);
+          dp = mfma16<T>(frag_rows<T>(sdO, qt, 0, fr, fg), K_.v0, dp);
+          dp = mfma16<T>(frag_rows<T>(sdO, qt, 1, fr, fg), K_.v1, dp);
           const f32x4 l4 = *(const f32x4*)(sLse + qt * 16 + fg * 4);
           const f32x4 d4 = *(const f32x4*)(sDel + qt * 16 + fg * 4);
 #pragma unroll
@@ -376,6 +423,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
         *(v4*)(gp + d + dt * 16) = wv;
       }
     }
+  };
+  if constexpr (PRELOAD) {
+#pragma unroll
+    for (int ki = 0; ki < MAXK; ++ki) {
+      if (wave + 4 * ki >= nkt_all) break;
+      process(wave + 4 * ki, pre[ki]);
+    }
+  } else {
+    for (int kt = wave; kt < nkt_all; kt += 4) process(kt, load_kv(kt));
   }
 }
 
@@ -418,12 +474,20 @@ static hipError_t bwd_t(const AttnBwdArgs& a, hipStream_t s) {
     case 14: return FN<T, 14, CAUSAL> ARGS;                         \
     case 16: return FN<T, 16, CAUSAL> ARGS;                         \
   }                                                                 \
+  if constexpr (!CAUSAL) {   /* long sequences exist only in the vision tower (ViT-L/14: 257 / 577 tokens) */ \
+    if (nkt == 18) return FN<T, 18, CAUSAL> ARGS;                   \
+    if (nkt == 38) return FN<T, 38, CAUSAL> ARGS;                   \
+  }                                                                 \
   return hipErrorInvalidValue;
 
 template <typename T, bool CAUSAL> static hipError_t fwd_n(int nkt, const AttnArgs& a, hipStream_t s) { MVLPT_NKT_SWITCH(fwd_t, (a, s)) }
 template <typename T, bool CAUSAL> static hipError_t bwd_n(int nkt, const AttnBwdArgs& a, hipStream_t s) { MVLPT_NKT_SWITCH(bwd_t, (a, s)) }
 
-static int nkt_for(int L) { int t = (L + 15) / 16; t += t & 1; return t < 2 ? 2 : t; }
+static int nkt_for(int L) {
+  int t = (L + 15) / 16; t += t & 1;
+  if (t > 18) return 38;
+  return t < 2 ? 2 : t;
+}
 
 hipError_t launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s) {
   if (a.L <= 0 || a.L > attn_max_len() || a.N <= 0) return hipErrorInvalidValue;

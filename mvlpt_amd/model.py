@@ -295,6 +295,40 @@ class MultitaskVLPromptLearner(nn.Module):
         return coop_emb, vpt_emb[0, :, :].unsqueeze(0), vpt_emb_deep
 
 
+# ------------------------------------------------------------------------------------------------ class sharding
+def _gather_class_shards(loc: torch.Tensor, cmax: int, world: int, n_cls: int) -> torch.Tensor:
+    """all-gather of per-rank text features [c_r, e] (c_r <= cmax) -> [n_cls, e] (RCCL over xGMI: <= 4.5 MB)."""
+    import torch.distributed as dist
+    e = loc.shape[1]
+    pad = torch.zeros(cmax, e, device=loc.device, dtype=loc.dtype)
+    pad[:loc.shape[0]] = loc
+    out = torch.empty(world * cmax, e, device=loc.device, dtype=loc.dtype)
+    dist.all_gather_into_tensor(out, pad)
+    rows = []
+    for r in range(world):
+        c_r = max(0, min(cmax, n_cls - r * cmax))
+        rows.append(out[r * cmax:r * cmax + c_r])
+    return torch.cat(rows, dim=0)
+
+
+def _scatter_class_grads(dtxt: torch.Tensor, lo: int, hi: int, cmax: int, world: int) -> torch.Tensor:
+    """reduce-scatter (sum) of d txt [n_cls, e] back to the class owners -> [hi-lo, e]."""
+    import torch.distributed as dist
+    n_cls, e = dtxt.shape
+    buf = torch.zeros(world * cmax, e, device=dtxt.device, dtype=dtxt.dtype)
+    for r in range(world):
+        c_r = max(0, min(cmax, n_cls - r * cmax))
+        buf[r * cmax:r * cmax + c_r] = dtxt[r * cmax:r * cmax + c_r]
+    if dist.get_backend() == "gloo":          # CPU tests: gloo has no reduce_scatter
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        rank = dist.get_rank()
+        own = buf[rank * cmax:(rank + 1) * cmax]
+    else:
+        own = torch.empty(cmax, e, device=dtxt.device, dtype=dtxt.dtype)
+        dist.reduce_scatter_tensor(own, buf, op=dist.ReduceOp.SUM)
+    return own[:hi - lo].contiguous()
+
+
 # ------------------------------------------------------------------------------------------------ autograd bridge
 class _PromptedClipFn(torch.autograd.Function):
     """CustomCLIP.forward as ONE autograd node: forward and backward are libmvlpt_hip.so calls."""
@@ -307,8 +341,18 @@ class _PromptedClipFn(torch.autograd.Function):
         need_txt = bool(fctx.needs_input_grad[4])
         need_img = bool(fctx.needs_input_grad[5] or fctx.needs_input_grad[6])
         run_text = not (coop_emb is None and model._const_text_features is not None)
-        side = model._side_stream if (run_text and model.overlap_towers) else None
-        if side is not None:
+        shard = model._class_shard if (run_text and coop_emb is not None) else None
+        side = model._side_stream if (run_text and model.overlap_towers and shard is None) else None
+        if shard is not None:
+            # Class-sharded text tower (collective 2): this rank encodes classes [lo, hi) only, the
+            # features are all-gathered; the backward reduce-scatters d(txt) back to the owners.
+            img = eng.image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
+            lo, hi, cmax, world = shard
+            ctx_loc = coop_emb if coop_emb.dim() == 2 else coop_emb[lo:hi]
+            loc = eng.text_fwd(pl.token_prefix[lo:hi], pl.token_suffix[lo:hi], ctx_loc, pl.layout[lo:hi], pl.eot[lo:hi],
+                               save_for_bwd=need_txt)
+            txt = _gather_class_shards(loc, cmax, world, pl.n_cls)
+        elif side is not None:
             # The two towers are independent until the logits: the text tower (few, small launches that cannot
             # fill 256 CUs) runs on a second HIP stream underneath the image tower's large GEMMs.
             main = torch.cuda.current_stream()
@@ -328,6 +372,7 @@ class _PromptedClipFn(torch.autograd.Function):
             model._const_text_features = txt     # no text context: features are constants
         logits = eng.logits_fwd(img, txt, model.logit_scale_exp, task_lo, task_hi)
         fctx.model, fctx.need_img, fctx.need_txt = model, need_img, need_txt
+        fctx.shard, fctx.ctx_shape = shard, (None if coop_emb is None else coop_emb.shape)
         fctx.has_deep = vpt_deep_emb is not None
         fctx.vpt_shape = None if vpt_emb is None else vpt_emb.shape
         return logits
@@ -337,7 +382,18 @@ class _PromptedClipFn(torch.autograd.Function):
         eng = fctx.model.engine
         dimg, dtxt = eng.logits_bwd(dlogits.contiguous(), fctx.need_img, fctx.need_txt)
         dctx = dvpt = ddeep = None
-        if fctx.need_txt:
+        if fctx.need_txt and fctx.shard is not None:
+            lo, hi, cmax, world = fctx.shard
+            # sum over ranks of d(local loss)/d(txt) for the classes this rank owns; the trainer's gradient
+            # all-reduce (mean over ranks) then yields d(global mean loss)/d(ctx) summed over all class shards
+            own = _scatter_class_grads(dtxt, lo, hi, cmax, world)
+            dloc = eng.text_bwd(own)
+            if len(fctx.ctx_shape) == 3:                      # class-specific contexts: only the owned rows are non-zero
+                dctx = torch.zeros(fctx.ctx_shape, device=dloc.device, dtype=dloc.dtype)
+                dctx[lo:hi] = dloc
+            else:
+                dctx = dloc
+        elif fctx.need_txt:
             dctx = eng.text_bwd(dtxt)
         if fctx.need_img:
             dvpt, ddeep = eng.image_bwd(dimg)
@@ -377,6 +433,7 @@ class CustomCLIP(nn.Module):
         self._const_text_features = None
         self.last_ncorrect = None
         self.overlap_towers = True
+        self._class_shard = None
         self._side_stream = torch.cuda.Stream(device=clip_model.device) if torch.cuda.is_available() else None
         self.multi_task_label_pertask = cfg.DATASET.MULTITASK_LABEL_PERTASK
         if self.multi_task_label_pertask:
@@ -389,6 +446,19 @@ class CustomCLIP(nn.Module):
                 s += len(dm._labelmap[task])
                 end[i] = s
             self.class_index_pertask_start, self.class_index_pertask_end = start, end
+
+    def enable_class_sharding(self, rank: int, world: int) -> None:
+        """Shard the text tower over classes across `world` data-parallel ranks (many-class configs: the text tower
+        costs C * L tokens per step independent of the batch, so replicating it caps weak scaling)."""
+        if world <= 1:
+            self._class_shard = None
+            return
+        C = self.prompt_learner.n_cls
+        cmax = (C + world - 1) // world
+        lo, hi = min(C, rank * cmax), min(C, (rank + 1) * cmax)
+        if hi <= lo:
+            raise ValueError("more ranks than classes: class sharding needs at least one class per rank")
+        self._class_shard = (lo, hi, cmax, world)
 
     def forward(self, image, task=None):
         coop_emb, vpt_emb, vpt_emb_deep = self.prompt_learner.forward_mvlpt_proj(self.dtype)

@@ -187,6 +187,14 @@ def make_full(mv, cm):
                      vpt_deep=True, cut_contextlen=True, **common)
 
 
+def make_large(mv, cm):
+    """BASELINE cfg5 family: ViT-L/14@336px (581 vision tokens with 4 prompts, 24 layers, width 1024; text width 768)."""
+    arch = ARCHS["ViT-L/14@336px"]
+    clip_model, _ = build_ref_clip(cm, arch, FULL_SEED)
+    run_case(mv, clip_model, name="full_vitl14_336_upt_cut", case_seed=41, coop_n_ctx=4, vpt_n_ctx=4, vpt_deep=True,
+             cut_contextlen=True, image_size=336, classnames=CLASSNAMES[:6], B=2, store_inputs=False)
+
+
 def make_tokens(mv):
     from clip import clip as refclip  # noqa
     tok = mv._tokenizer
@@ -215,6 +223,8 @@ def main():
         make_tiny(mv, cm)
     if "full" in which:
         make_full(mv, cm)
+    if "large" in which:
+        make_large(mv, cm)
 
 
 if __name__ == "__main__":

@@ -142,7 +142,8 @@ def test_features_match_reference(tiny_clip_fp16):
 
 
 FULL = [("ViT-B/32", "full_vitb32_coop_end"), ("ViT-B/16", "full_vitb16_coop_middle"),
-        ("ViT-B/16", "full_vitb16_vpt_deep"), ("ViT-B/16", "full_vitb16_upt_cut")]
+        ("ViT-B/16", "full_vitb16_vpt_deep"), ("ViT-B/16", "full_vitb16_upt_cut"),
+        ("ViT-L/14@336px", "full_vitl14_336_upt_cut")]     # BASELINE cfg5 family: 581 vision tokens, 24 layers
 _full_clips = {}
 
 
@@ -159,8 +160,9 @@ def test_full_size_case_fp16(arch_name, name):
         _full_clips[arch_name] = (FrozenCLIP(sd, compute_dtype="fp16"), sd)
     clip, sd = _full_clips[arch_name]
     case = load_npz(name)
-    image, pre, suf = full_case_inputs(case, sd)
-    model = build_model(case, clip, 224, pre, suf)
+    res = ARCHS[arch_name].image_resolution
+    image, pre, suf = full_case_inputs(case, sd, res)
+    model = build_model(case, clip, res, pre, suf)
     err, worst = run_case(case, model, image, TOL_FP16, GRAD_TOL_FP16)
     with torch.no_grad():
         pl = model.prompt_learner

@@ -97,7 +97,8 @@ def _attn_ref(qkv, N, L, H, causal):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("L,causal", [(5, False), (5, True), (24, True), (50, False), (77, True), (197, False), (205, False), (256, False)])
+@pytest.mark.parametrize("L,causal", [(5, False), (5, True), (24, True), (50, False), (77, True), (197, False), (205, False), (256, False),
+                                      (261, False), (581, False)])   # ViT-L/14 @224 / @336 (+4 prompts): online-softmax blocks
 def test_attention_fwd_bwd(dtype, L, causal):
     E = _eng()
     N, H = 3, 2
