@@ -6,10 +6,11 @@
 // stores W as [N,K] so the forward reads it as-is; the dX GEMM reads the pre-transposed copy packed
 // once at load time (weights are frozen, trainers/mvlpt.py:855-858).
 //
-// gfx950 design: one kernel template, two geometries.  Every wave owns a 64x64 output block = 4x4 MFMA
-// 16x16x32 accumulators (fp32); BK = 64.
+// gfx950 design: one kernel template, three geometries, BK = 64, MFMA 16x16x32 with fp32 accumulators.
+//   huge  : 256x256 tile, 8 waves (2x4) of 128x64 (8x4 accumulators), one workgroup per CU, 2-deep ring (128 KiB):
+//           fewest LDS-DMA instructions and LDS reads per FLOP; for the wide GEMMs (QKV, MLP up) with >= 4 rounds.
 //   big   : 256x128 tile, 512 threads = 8 waves (4x2), ONE workgroup per CU, 3-deep LDS ring (144 KiB) with
-//           COUNTED s_waitcnt vmcnt: the loads of K-stage f+2 stay in flight across the barrier that ends
+//           waves of 64x64 (4x4 accumulators), COUNTED s_waitcnt vmcnt: the loads of K-stage f+2 stay in flight across the barrier that ends
 //           stage f (raw s_barrier + lgkmcnt(0), never __syncthreads, which would drain the DMA queue).
 //   small : 128x128 tile, 256 threads = 4 waves (2x2), two workgroups per CU, 2-deep ring, for GEMMs with too
 //           few 256x128 tiles to fill 256 CUs (the text tower, CLS-row projections).
@@ -24,7 +25,7 @@
 
 namespace mvlpt {
 
-constexpr int BN = 128, BK = 64;
+constexpr int BK = 64;
 
 // Epilogue: the MFMA result layout gives every lane 4 consecutive columns of 16 different rows, i.e. 8-byte
 // pieces scattered over 16 rows per store instruction.  With ~0.8 GFLOP per MB of output (short K) the L2
@@ -131,10 +132,13 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
 // the tile list in rounds and keep the LDS-DMA pipeline running ACROSS tile boundaries (the first K-stages of the
 // next tile are in flight while the current tile finishes and its epilogue is stored), so the short-K GEMMs of
 // this path (K = 768 / 512) do not pay a load bubble per tile.
-template <typename T, int EPI, int BM_, int NW, int NS>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void gemm_bt_kernel(GemmArgs g) {
+template <typename T, int EPI, int BM_, int BN_, int NW, int NS>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_bt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using v8 = typename Vec<T>::v8;
+  constexpr int BN = BN_;
+  constexpr int WCN = BN_ / 64, WCM = NW / WCN;       // waves along N / M
+  constexpr int WMF = BM_ / WCM / 16;                 // 16-row A fragments per wave (4: 64x64 wave tile, 8: 128x64)
   constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int A_IT = BM_ / 8 / NW, B_IT = BN / 8 / NW, LOADS = A_IT + B_IT;
   const int tid = threadIdx.x;
@@ -202,9 +206,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void gemm_bt_kernel(GemmA
   };
 
   // ---- fragment addressing ------------------------------------------------------------------------
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WCN, wn = wave % WCN;
   const int fr = lane & 15, fg = lane >> 4;
-  const int a_off = (wm * 64 + fr) * 128;
+  const int a_off = (wm * (WMF * 16) + fr) * 128;
   const int b_off = A_BYTES + (wn * 64 + fr) * 128;
   const int c0 = ((0 + fg) ^ (fr & 7)) * 16;        // k-step 0 chunk
   const int c1 = ((4 + fg) ^ (fr & 7)) * 16;        // k-step 1 chunk
@@ -223,11 +227,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void gemm_bt_kernel(GemmA
   int slot = 0;
   int t = tile_of(0);
   for (int round = 0; t < ntiles; t = tile_of(++round)) {
-    f32x4 acc[4][4];
+    f32x4 acc[WMF / 4][4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WMF; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) acc[i >> 2][i & 3][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nk; ++kt) {
       // K-stage f + NS - 1 goes to the slot freed by the last barrier.  An LDS-DMA instruction costs its wave
@@ -241,16 +245,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void gemm_bt_kernel(GemmA
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int c = ks ? c1 : c0;
-        v8 af[4], bf[4];
+        v8 af[WMF], bf[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          af[i] = *(const v8*)(base + a_off + i * 2048 + c);
-          bf[i] = *(const v8*)(base + b_off + i * 2048 + c);
-        }
+        for (int i = 0; i < 4; ++i) bf[i] = *(const v8*)(base + b_off + i * 2048 + c);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WMF; ++i) af[i] = *(const v8*)(base + a_off + i * 2048 + c);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(bf[j], af[i], acc[i][j]);
+        for (int i = 0; i < WMF; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i >> 2][i & 3][j] = mfma16<T>(bf[j], af[i], acc[i >> 2][i & 3][j]);
       }
       if (!dma_first) issued = issue();
       // the NEXT stage must have landed (own loads) before the barrier; the one just issued may stay in flight
@@ -264,18 +267,20 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void gemm_bt_kernel(GemmA
     // and fence the scratch reads of all waves against that DMA with one more barrier
     int tm, tn;
     tile_mn(t, tm, tn);
-    epilogue_store<T, EPI>(g, acc, tm * BM_ + wm * 64, tn * BN + wn * 64, lane,
-                           smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE);
+#pragma unroll
+    for (int hh = 0; hh < WMF / 4; ++hh)
+      epilogue_store<T, EPI>(g, acc[hh], tm * BM_ + wm * (WMF * 16) + hh * 64, tn * BN + wn * 64, lane,
+                             smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE);
     __builtin_amdgcn_s_barrier();
   }
 }
 
-template <typename T, int EPI, int BM_, int NW, int NS>
+template <typename T, int EPI, int BM_, int BN_, int NW, int NS>
 static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
-  constexpr int LDS = NS * (BM_ + BN) * BK * 2;
+  constexpr int LDS = NS * (BM_ + BN_) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, NW, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   static int cus = 0;
@@ -284,9 +289,9 @@ static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hi
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   }
-  const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN - 1) / BN);
+  const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
   const int resident = cus * wg_per_cu;
-  hipExtLaunchKernelGGL((gemm_bt_kernel<T, EPI, BM_, NW, NS>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), LDS, s,
+  hipExtLaunchKernelGGL((gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), LDS, s,
                         ea, eb, 0, g);
   return hipGetLastError();
 }
@@ -294,10 +299,14 @@ static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hi
 template <typename T, int EPI>
 static hipError_t launch_t(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
   // big geometry when its tiles fill the chip at least ~1.5 times; otherwise the 128x128 geometry
-  const long big_tiles = (long)((g.M + 255) / 256) * ((g.N + BN - 1) / BN);
-  static const int use_big = getenv("MVLPT_GEMM_BIG") ? atoi(getenv("MVLPT_GEMM_BIG")) : 1;   // experiment switch
-  if (big_tiles >= 384 && use_big) return launch_geo<T, EPI, 256, 8, 3>(g, 1, s, ea, eb);
-  return launch_geo<T, EPI, 128, 4, 2>(g, 2, s, ea, eb);
+  // geometry by tile count: 256x256 (128x64 wave tiles, least LDS-DMA / LDS-read traffic per FLOP) needs >= 4 full
+  // rounds of 256 resident workgroups to amortise its tail; 256x128 needs >= 1.5 rounds; otherwise 128x128.
+  const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+  const long t256 = (long)((g.M + 255) / 256) * (g.N / 256);
+  static const int geo = getenv("MVLPT_GEMM_GEO") ? atoi(getenv("MVLPT_GEMM_GEO")) : 2;   // experiment switch (0,1,2)
+  if (geo >= 2 && g.N % 256 == 0 && t256 >= 1024) return launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
+  if (geo >= 1 && t128 >= 384) return launch_geo<T, EPI, 256, 128, 8, 3>(g, 1, s, ea, eb);
+  return launch_geo<T, EPI, 128, 128, 4, 2>(g, 2, s, ea, eb);
 }
 
 template <typename T>
@@ -314,7 +323,7 @@ static hipError_t launch_epi(const GemmArgs& g, int epi, hipStream_t s, hipEvent
 
 // K must be a multiple of 64 and N of 128 (every CLIP width is; conv K is zero-padded); M is arbitrary.
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
-  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N % BN) != 0) return hipErrorInvalidValue;
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N % 128) != 0) return hipErrorInvalidValue;
   if (epi == EPI_RESID32 && !g.resid) return hipErrorInvalidValue;
   if (epi == EPI_GELUBWD && !g.aux) return hipErrorInvalidValue;
   if (dtype == DT_F16) return launch_epi<f16>(g, epi, s, ea, eb);
