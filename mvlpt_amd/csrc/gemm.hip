@@ -224,6 +224,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bt_kernel(GemmArgs g) {
   }
   __builtin_amdgcn_s_barrier();
 
+  // lower bound of the global STORE instructions one full-tile epilogue issues per wave (8 x 16 B for 16-bit outputs
+  // of a 64x64 block, 16 for fp32-staged ones); used only when every row of the tile exists (no masked-off stores)
+  constexpr int ST_MIN = (WMF / 4) * ((EPI == EPI_STORE16 || EPI == EPI_GELU) ? 8 : 16);
+  bool stores_pending = false;
   int slot = 0;
   int t = tile_of(0);
   for (int round = 0; t < ntiles; t = tile_of(++round)) {
@@ -242,23 +246,53 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bt_kernel(GemmArgs g) {
       bool issued = false;
       if (dma_first) issued = issue();
       const char* base = smem + slot * STAGE;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      // Register-double-buffered fragment pipeline: the ds_reads of MFMA group s+1 (two A fragments, plus the four
+      // B fragments when the k-step changes) are issued BEFORE the 8 MFMAs of group s, so hipcc's counted lgkmcnt
+      // lets the LDS latency run under the matrix pipe instead of in front of every 8-MFMA burst.
+      constexpr int PAIRS = WMF / 2, GROUPS = 2 * PAIRS;
+      v8 bfr[2][4], afr[2][2];
+      auto load_b = [&](int ks, v8 (&bf)[4]) {
         const int c = ks ? c1 : c0;
-        v8 af[WMF], bf[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bf[i] = *(const v8*)(base + b_off + i * 2048 + c);
+        for (int j = 0; j < 4; ++j) bf[j] = *(const v8*)(base + b_off + j * 2048 + c);
+      };
+      auto load_a2 = [&](int ks, int pair, v8 (&af)[2]) {
+        const int c = ks ? c1 : c0;
 #pragma unroll
-        for (int i = 0; i < WMF; ++i) af[i] = *(const v8*)(base + a_off + i * 2048 + c);
+        for (int i = 0; i < 2; ++i) af[i] = *(const v8*)(base + a_off + (pair * 2 + i) * 2048 + c);
+      };
+      load_b(0, bfr[0]);
+      load_a2(0, 0, afr[0]);
 #pragma unroll
-        for (int i = 0; i < WMF; ++i)
+      for (int sg = 0; sg < GROUPS; ++sg) {
+        const int ks = sg / PAIRS, pair = sg % PAIRS, cur = sg & 1;
+        if (sg + 1 < GROUPS) {
+          const int nks = (sg + 1) / PAIRS, npair = (sg + 1) % PAIRS;
+          if (npair == 0) load_b(nks, bfr[nks & 1]);
+          load_a2(nks, npair, afr[cur ^ 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i >> 2][i & 3][j] = mfma16<T>(bf[j], af[i], acc[i >> 2][i & 3][j]);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int ai = pair * 2 + i;
+            acc[ai >> 2][ai & 3][j] = mfma16<T>(bfr[ks & 1][j], afr[cur][i], acc[ai >> 2][ai & 3][j]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (!dma_first) issued = issue();
-      // the NEXT stage must have landed (own loads) before the barrier; the one just issued may stay in flight
-      if (NS == 3 && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the NEXT stage must have landed (own loads) before the barrier; the one just issued may stay in flight.
+      // vmcnt retires in order and counts stores: right after an epilogue the youngest operations are its ST_MIN
+      // global stores followed by the DMA just issued, so allowing ST_MIN + LOADS operations in flight still
+      // guarantees the older DMA has landed without making the wave wait for its own output stores.
+      if (NS == 3 && issued) {
+        if (stores_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + ST_MIN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      stores_pending = false;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       slot = slot + 1 == NS ? 0 : slot + 1;
@@ -272,6 +306,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bt_kernel(GemmArgs g) {
       epilogue_store<T, EPI>(g, acc[hh], tm * BM_ + wm * (WMF * 16) + hh * 64, tn * BN + wn * 64, lane,
                              smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE);
     __builtin_amdgcn_s_barrier();
+    stores_pending = (tm + 1) * BM_ <= M;
   }
 }
 
