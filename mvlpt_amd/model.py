@@ -334,13 +334,25 @@ class _PromptedClipFn(torch.autograd.Function):
     """CustomCLIP.forward as ONE autograd node: forward and backward are libmvlpt_hip.so calls."""
 
     @staticmethod
-    def forward(fctx, model: "CustomCLIP", image, task_lo, task_hi, coop_emb, vpt_emb, vpt_deep_emb):
+    def forward(fctx, model: "CustomCLIP", image, task_lo, task_hi, coop_emb, vpt_emb, vpt_deep_emb, grad_on=True):
         eng = model.engine
         pl = model.prompt_learner
         # (grad mode is off inside Function.forward: ask autograd which inputs need a gradient)
-        need_txt = bool(fctx.needs_input_grad[4])
-        need_img = bool(fctx.needs_input_grad[5] or fctx.needs_input_grad[6])
-        run_text = not (coop_emb is None and model._const_text_features is not None)
+        # `grad_on` = torch.is_grad_enabled() at the call site (needs_input_grad ignores torch.no_grad())
+        need_txt = grad_on and bool(fctx.needs_input_grad[4])
+        need_img = grad_on and bool(fctx.needs_input_grad[5] or fctx.needs_input_grad[6])
+        # inference: the text features depend only on the prompt parameters -> computed once per parameter version
+        # instead of once per batch as the reference does (trainers/mvlpt.py:546-548 under test(), :989-1088)
+        ver = None
+        if not pl.training and not need_txt and coop_emb is not None:   # Dassl sets the mode on the registered prompt_learner
+            ver = tuple((id(p), p._version) for p in model.prompt_learner.parameters())
+            if model._eval_text_cache is not None and model._eval_text_cache[0] == ver:
+                model._const_text_features, cached_eval = model._eval_text_cache[1], True
+            else:
+                cached_eval = False
+        else:
+            cached_eval = False
+        run_text = not ((coop_emb is None or cached_eval) and model._const_text_features is not None)
         shard = model._class_shard if (run_text and coop_emb is not None) else None
         side = model._side_stream if (run_text and model.overlap_towers and shard is None) else None
         if shard is not None:
@@ -370,6 +382,10 @@ class _PromptedClipFn(torch.autograd.Function):
             txt = model._const_text_features
         elif coop_emb is None:
             model._const_text_features = txt     # no text context: features are constants
+        if ver is not None:
+            model._eval_text_cache = (ver, txt)
+        if coop_emb is not None:
+            model._const_text_features = None    # only the no-context case may persist across training steps
         logits = eng.logits_fwd(img, txt, model.logit_scale_exp, task_lo, task_hi)
         fctx.model, fctx.need_img, fctx.need_txt = model, need_img, need_txt
         fctx.shard, fctx.ctx_shape = shard, (None if coop_emb is None else coop_emb.shape)
@@ -398,7 +414,7 @@ class _PromptedClipFn(torch.autograd.Function):
         if fctx.need_img:
             dvpt, ddeep = eng.image_bwd(dimg)
             dvpt = dvpt.view(fctx.vpt_shape)
-        return None, None, None, None, dctx, dvpt, ddeep
+        return None, None, None, None, dctx, dvpt, ddeep, None
 
 
 class _CrossEntropyFn(torch.autograd.Function):
@@ -434,6 +450,7 @@ class CustomCLIP(nn.Module):
         self.last_ncorrect = None
         self.overlap_towers = True
         self._class_shard = None
+        self._eval_text_cache = None
         self._side_stream = torch.cuda.Stream(device=clip_model.device) if torch.cuda.is_available() else None
         self.multi_task_label_pertask = cfg.DATASET.MULTITASK_LABEL_PERTASK
         if self.multi_task_label_pertask:
@@ -467,7 +484,7 @@ class CustomCLIP(nn.Module):
             t = task.cpu().long() if torch.is_tensor(task) else torch.as_tensor(task).long()
             lo = self.class_index_pertask_start[t].to(torch.int32).to(image.device)
             hi = self.class_index_pertask_end[t].to(torch.int32).to(image.device)
-        return _PromptedClipFn.apply(self, image, lo, hi, coop_emb, vpt_emb, vpt_emb_deep)
+        return _PromptedClipFn.apply(self, image, lo, hi, coop_emb, vpt_emb, vpt_emb_deep, torch.is_grad_enabled())
 
     def cross_entropy(self, logits, label):
         """HIP replacement for ``F.cross_entropy(output, label)`` (trainers/mvlpt.py:931)."""

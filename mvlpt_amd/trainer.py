@@ -299,6 +299,44 @@ class MVLPT(TrainerX):
     def model_inference(self, input, task=None):
         return self.model(input, task=task)
 
+    @torch.no_grad()
+    def test(self, split=None):
+        """Generic testing pipeline (trainers/mvlpt.py:989-1088, CoOp-data branch): top-1 accuracy overall and, for
+        multitask runs, per task on the task's own class range (:1035-1039).  Returns the headline accuracy (%)."""
+        self.set_model_mode("eval")
+        split = split or self.cfg.TEST.SPLIT
+        loader = self.val_loader if (split == "val" and self.val_loader is not None) else self.test_loader
+        correct = torch.zeros((), device=self.device)
+        total = 0
+        per_task = {}
+        for batch in loader:
+            input, label, tasks_ = self.parse_batch_test(batch)
+            output = self.model_inference(input, task=tasks_)
+            if label.dim() > 1:
+                label = label.argmax(dim=1)
+            correct += (output.argmax(dim=1) == label).sum()
+            total += label.shape[0]
+            if tasks_ is not None and getattr(self.dm, "task_class_counts", None):
+                counts = self.dm.task_class_counts
+                starts = [0]
+                for c in counts[:-1]:
+                    starts.append(starts[-1] + c)
+                for t_id in set(tasks_.tolist()):
+                    sel = (tasks_ == t_id).to(output.device)
+                    lo, hi = starts[t_id], starts[t_id] + counts[t_id]
+                    hit = (output[sel][:, lo:hi].argmax(dim=1) + lo == label[sel]).sum()
+                    acc = per_task.setdefault(t_id, [torch.zeros((), device=self.device), 0])
+                    acc[0] += hit
+                    acc[1] += int(sel.sum())
+        results = {"accuracy": 100.0 * float(correct) / max(total, 1)}
+        if per_task:
+            accs = {self.dm._task_names[t]: 100.0 * float(c) / max(n, 1) for t, (c, n) in per_task.items()}
+            key = self.cfg.DATASET.MULTITASK_EVALKEY
+            results = {"average": sum(accs.values()) / len(accs)} if key == "average" else {key: accs[key]}
+            self.last_task_results = accs
+        self.last_results = results
+        return list(results.values())[0]
+
     def load_model(self, directory, epoch=None):
         if not directory:
             print("Note that load_model() is skipped as no pretrained model is given")
