@@ -165,7 +165,7 @@ def main():
     # tower; concurrent kernels stretch each other's durations, which inflates per-launch times (they then sum
     # to more than the step) without being slower overall.  Reported next to the timed-region figure.
     stats_serial = {}
-    if timing and rank == 0 and trainer.model.overlap_towers:
+    if timing and trainer.model.overlap_towers:      # every rank takes part (the step contains the gradient all-reduce)
         trainer.model.overlap_towers = False
         step(0)
         torch.cuda.synchronize()
