@@ -114,8 +114,38 @@ __global__ void patchify_kernel(const TI* __restrict__ img, T* __restrict__ out,
     *(typename Vec<T>::v8*)(out + row * Kp + cb * 8) = w;
   }
 }
+// fast path: fp32 image, P % 8 == 0 (ViT-B/16, B/32): 8 consecutive kx are 32 contiguous bytes of one image row
+template <typename T>
+__global__ void patchify_vec_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int R, int P, int Kp) {
+  const int G = R / P, K = 3 * P * P, PP = P * P;
+  const size_t n8 = (size_t)B * G * G * (Kp / 8);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const int cb = (int)(i % (Kp / 8));
+    const size_t row = i / (Kp / 8);
+    const int gx = (int)(row % G), gy = (int)((row / G) % G), b = (int)(row / ((size_t)G * G));
+    typename Vec<T>::v8 w;
+    const int col = cb * 8;
+    if (col < K) {
+      const int c = col / PP, ky = (col % PP) / P, kx = col % P;
+      const float* p = img + (((size_t)b * 3 + c) * R + gy * P + ky) * R + gx * P + kx;
+      const f32x4 v0 = *(const f32x4*)p, v1 = *(const f32x4*)(p + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { w[e] = (T)v0[e]; w[e + 4] = (T)v1[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] = (T)0.f;
+    }
+    *(typename Vec<T>::v8*)(out + row * Kp + col) = w;
+  }
+}
 template <typename T>
 static hipError_t patchify_t(const void* image, int image_dtype, T* out, int B, int R, int P, int Kp, hipStream_t s) {
+  if (image_dtype == DT_F32 && P % 8 == 0 && R % 4 == 0) {
+    const size_t n8v = (size_t)B * (R / P) * (R / P) * (Kp / 8);
+    const int gridv = (int)((n8v + 255) / 256 < 16384 ? (n8v + 255) / 256 : 16384);
+    hipLaunchKernelGGL((patchify_vec_kernel<T>), dim3(gridv), dim3(256), 0, s, (const float*)image, out, B, R, P, Kp);
+    return hipGetLastError();
+  }
   const int G = R / P;
   const size_t n8 = (size_t)B * G * G * (Kp / 8);
   const int grid = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
@@ -152,31 +182,43 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __res
   const int pi = i == 0 ? 0 : i - n_vpt;                    // positional row
   const float* src = i == 0 ? cls : pe + ((size_t)b * G2 + (pi - 1)) * d;
   const float* pp = pos + (size_t)pi * d;
+  constexpr int MAXV = 8;                                   // d <= 2048, row held in registers
+  f32x4 v[MAXV];
   float s = 0.f;
-  for (int c = lane * 4; c < d; c += 256) {
-    const f32x4 v = *(const f32x4*)(src + c) + *(const f32x4*)(pp + c);
-    s += v[0] + v[1] + v[2] + v[3];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < d) {
+      v[k] = *(const f32x4*)(src + c) + *(const f32x4*)(pp + c);
+      s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    }
   }
   const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
-  for (int c = lane * 4; c < d; c += 256) {
-    const f32x4 v = *(const f32x4*)(src + c) + *(const f32x4*)(pp + c);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const float t = v[e] - mean; q += t * t; }
+  for (int k = 0; k < MAXV; ++k) {
+    if ((k * 64 + lane) * 4 < d) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float t = v[k][e] - mean; q += t * t; }
+    }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
-  for (int c = lane * 4; c < d; c += 256) {
-    const f32x4 v = *(const f32x4*)(src + c) + *(const f32x4*)(pp + c);
-    const f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(bt + c);
-    f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e] + bb[e];
-    *(f32x4*)(xo + c) = o;
+  for (int k = 0; k < MAXV; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < d) {
+      const f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(bt + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mean) * rstd * gg[e] + bb[e];
+      *(f32x4*)(xo + c) = o;
+    }
   }
 }
 hipError_t launch_assemble_tokens(const float* patch_emb, const float* cls, const float* pos, const float* g, const float* b,
                                   const float* vpt, int n_vpt, float* x, int B, int G2, int d, hipStream_t s) {
-  if (d % 4) return hipErrorInvalidValue;
+  if (d % 4 || d > 2048) return hipErrorInvalidValue;
   const size_t rows = (size_t)B * (1 + n_vpt + G2);
   hipLaunchKernelGGL(assemble_tokens_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, patch_emb, cls, pos, g, b, vpt,
                      n_vpt, x, B, G2, d);
@@ -445,69 +487,68 @@ hipError_t launch_cross_entropy(const float* logits, const void* labels, int lab
 }
 
 // d imn = scale * (dlogits*mask) txn ; d txn = scale * (dlogits*mask)^T imn ; then through x/||x||.
-__global__ __launch_bounds__(256) void logits_bwd_img_kernel(const float* __restrict__ dl, const float* __restrict__ imn,
-                                                             const float* __restrict__ txn, const float* __restrict__ inorm,
-                                                             float scale, const int32_t* __restrict__ lo,
-                                                             const int32_t* __restrict__ hi, float* __restrict__ dimg,
-                                                             int B, int C, int e) {
+// One workgroup per output row (image b / class c); its 4 waves split the reduction axis (classes / images), every
+// lane owns 8 consecutive feature columns (e <= 1024 = 2 x 64 lanes x 8), partial rows are combined through LDS.
+template <bool IMG>
+__global__ __launch_bounds__(256) void logits_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ imn,
+                                                         const float* __restrict__ txn, const float* __restrict__ norm,
+                                                         float scale, const int32_t* __restrict__ lo,
+                                                         const int32_t* __restrict__ hi, float* __restrict__ dout,
+                                                         int B, int C, int e) {
+  __shared__ float part[4][1024];
   __shared__ float red[4];
-  const int b = blockIdx.x;
-  const int c_lo = lo ? lo[b] : 0, c_hi = lo ? hi[b] : C;
-  float dot = 0.f;
-  // each thread owns columns i = tid, tid+256, ... ; keep d(imn) in registers (e <= 1024)
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int c = c_lo; c < c_hi; ++c) {
-    const float w = scale * dl[(size_t)b * C + c];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x;                       // b (IMG) or c
+  const float* other = IMG ? txn : imn;             // rows of the other side, indexed by the reduction index
+  const float* self = (IMG ? imn : txn) + (size_t)row * e;
+  const int nred = IMG ? C : B;
+  f32x4 acc[2][2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int i = threadIdx.x + k * 256; if (i < e) g[k] += w * txn[(size_t)c * e + i]; }
+  for (int k = 0; k < 2; ++k) { acc[k][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int r = wave; r < nred; r += 4) {
+    const int b = IMG ? row : r, c = IMG ? r : row;
+    if (lo && !(c >= lo[b] && c < hi[b])) continue;     // multiplicative 0/1 task mask
+    const float w = scale * dl[(size_t)b * C + c];
+    const float* o = other + (size_t)r * e;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = (k * 64 + lane) * 8;
+      if (i < e) {
+        acc[k][0] += w * *(const f32x4*)(o + i);
+        acc[k][1] += w * *(const f32x4*)(o + i + 4);
+      }
+    }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { const int i = threadIdx.x + k * 256; if (i < e) dot += g[k] * imn[(size_t)b * e + i]; }
-  dot = wave_sum(dot);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  for (int k = 0; k < 2; ++k) {
+    const int i = (k * 64 + lane) * 8;
+    if (i < e) { *(f32x4*)&part[wave][i] = acc[k][0]; *(f32x4*)&part[wave][i + 4] = acc[k][1]; }
+  }
   __syncthreads();
-  dot = red[0] + red[1] + red[2] + red[3];
-  const float inv = 1.0f / inorm[b];
+  float g[4], dot = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int i = threadIdx.x + k * 256;
-    if (i < e) dimg[(size_t)b * e + i] = (g[k] - imn[(size_t)b * e + i] * dot) * inv;
+    g[k] = 0.f;
+    if (i < e) { g[k] = part[0][i] + part[1][i] + part[2][i] + part[3][i]; dot += g[k] * self[i]; }
   }
-}
-__global__ __launch_bounds__(256) void logits_bwd_txt_kernel(const float* __restrict__ dl, const float* __restrict__ imn,
-                                                             const float* __restrict__ txn, const float* __restrict__ tnorm,
-                                                             float scale, const int32_t* __restrict__ lo,
-                                                             const int32_t* __restrict__ hi, float* __restrict__ dtxt,
-                                                             int B, int C, int e) {
-  __shared__ float red[4];
-  const int c = blockIdx.x;
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < B; ++b) {
-    if (lo && !(c >= lo[b] && c < hi[b])) continue;
-    const float w = scale * dl[(size_t)b * C + c];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const int i = threadIdx.x + k * 256; if (i < e) g[k] += w * imn[(size_t)b * e + i]; }
-  }
-  float dot = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { const int i = threadIdx.x + k * 256; if (i < e) dot += g[k] * txn[(size_t)c * e + i]; }
   dot = wave_sum(dot);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  if (lane == 0) red[wave] = dot;
   __syncthreads();
   dot = red[0] + red[1] + red[2] + red[3];
-  const float inv = 1.0f / tnorm[c];
+  const float inv = 1.0f / norm[row];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int i = threadIdx.x + k * 256;
-    if (i < e) dtxt[(size_t)c * e + i] = (g[k] - txn[(size_t)c * e + i] * dot) * inv;
+    if (i < e) dout[(size_t)row * e + i] = (g[k] - self[i] * dot) * inv;
   }
 }
 hipError_t launch_logits_bwd(const float* dlogits, const float* imn, const float* txn, const float* inorm, const float* tnorm,
                              float scale, const int32_t* lo, const int32_t* hi, float* dimg, float* dtxt, int B, int C, int e,
                              hipStream_t s) {
-  if (e > 1024) return hipErrorInvalidValue;
-  if (dimg) hipLaunchKernelGGL(logits_bwd_img_kernel, dim3(B), dim3(256), 0, s, dlogits, imn, txn, inorm, scale, lo, hi, dimg, B, C, e);
-  if (dtxt) hipLaunchKernelGGL(logits_bwd_txt_kernel, dim3(C), dim3(256), 0, s, dlogits, imn, txn, tnorm, scale, lo, hi, dtxt, B, C, e);
+  if (e > 1024 || e % 8) return hipErrorInvalidValue;
+  if (dimg) hipLaunchKernelGGL(logits_bwd_kernel<true>, dim3(B), dim3(256), 0, s, dlogits, imn, txn, inorm, scale, lo, hi, dimg, B, C, e);
+  if (dtxt) hipLaunchKernelGGL(logits_bwd_kernel<false>, dim3(C), dim3(256), 0, s, dlogits, imn, txn, tnorm, scale, lo, hi, dtxt, B, C, e);
   return hipGetLastError();
 }
 
