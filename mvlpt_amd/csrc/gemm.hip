@@ -35,9 +35,27 @@ constexpr int BK = 64;
 // combined with another global operand in fp32 (residual, GELU' * u) is staged as fp32, 16 rows per pass.
 constexpr int EPI_SCRATCH_PER_WAVE = 4608;   // 32 rows x (128 + 16) B  >=  16 rows x (256 + 16) B
 
-template <typename T, int EPI>
+// wave-private scratch rows: either one contiguous region, or (phased kernel) the wave's OWN six 1-KiB LDS-DMA slabs
+// of the ring slot that was just released (rows do not straddle slabs)
+template <int RS>
+struct LinearRows {
+  char* base;
+  __device__ __forceinline__ char* operator()(int r) const { return base + r * RS; }
+};
+template <int RS>
+struct SlabRows {
+  static constexpr int RPS = 1024 / RS;      // rows per slab (7 at 144 B, 3 at 272 B)
+  char* slot; int wave; int a_bytes;
+  __device__ __forceinline__ char* operator()(int r) const {
+    const int sl = r / RPS, k = r - sl * RPS;
+    const int off = sl < 4 ? (sl * 8 + wave) * 1024 : a_bytes + ((sl - 4) * 8 + wave) * 1024;
+    return slot + off + k * RS;
+  }
+};
+
+template <typename T, int EPI, typename Rows16, typename Rows32>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&acc)[4][4], int mbase, int nbase, int lane,
-                                               char* scratch /* wave-private, 16-B aligned */) {
+                                               Rows16 rows16, Rows32 rows32) {
   using v4 = typename Vec<T>::v4;
   using v8 = typename Vec<T>::v8;
   const int M = g.M, N = g.N;      // N % 128 == 0 (checked at launch): no column guard
@@ -50,7 +68,6 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
     for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + nbase + j * 16 + fg * 4);
   }
   if constexpr (EPI == EPI_STORE16 || EPI == EPI_GELU) {
-    constexpr int RS = 144;                                   // scratch row stride (bytes)
     constexpr int NOUT = (EPI == EPI_GELU) ? 2 : 1;
 #pragma unroll
     for (int which = 0; which < NOUT; ++which) {
@@ -68,14 +85,14 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
             v4 w;
 #pragma unroll
             for (int e = 0; e < 4; ++e) w[e] = from_f32<T>((EPI == EPI_GELU && which == 0) ? quick_gelu(v[e]) : v[e]);
-            *(v4*)(scratch + (ii * 16 + fr) * RS + (j * 16 + fg * 4) * 2) = w;
+            *(v4*)(rows16(ii * 16 + fr) + (j * 16 + fg * 4) * 2) = w;
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int r = it * 8 + (lane >> 3), c = lane & 7;   // 8 lanes x 16 B = one 128-B row segment
-          const v8 w = *(const v8*)(scratch + r * RS + c * 16);
+          const v8 w = *(const v8*)(rows16(r) + c * 16);
           const int m = mbase + half * 32 + r;
           if (m < M) __builtin_nontemporal_store(w, (v8*)(outp + (size_t)m * N + nbase + c * 8));
         }
@@ -83,7 +100,6 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
       }
     }
   } else {
-    constexpr int RS = 272;
     const int c = lane & 15, rq = lane >> 4;                  // 16 lanes x 16 B = one 256-B row segment (fp32)
     // Every global LOAD of the epilogue is issued before its first store: hipcc waits vmcnt(0) on an ordinary
     // load while LDS-DMA is in flight, and that wait would also drain the stores issued before it.
@@ -103,12 +119,12 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *(f32x4*)(scratch + fr * RS + (j * 16 + fg * 4) * 4) = acc[i][j] + bv[j];
+      for (int j = 0; j < 4; ++j) *(f32x4*)(rows32(fr) + (j * 16 + fg * 4) * 4) = acc[i][j] + bv[j];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int r = it * 4 + rq;
-        f32x4 v = *(const f32x4*)(scratch + r * RS + c * 16);
+        f32x4 v = *(const f32x4*)(rows32(r) + c * 16);
         const int m = mbase + i * 16 + r;
         const size_t o = (size_t)m * N + nbase + c * 4;
         if constexpr (EPI == EPI_RESID32) {
@@ -304,10 +320,177 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bt_kernel(GemmArgs g) {
 #pragma unroll
     for (int hh = 0; hh < WMF / 4; ++hh)
       epilogue_store<T, EPI>(g, acc[hh], tm * BM_ + wm * (WMF * 16) + hh * 64, tn * BN + wn * 64, lane,
-                             smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE);
+                             LinearRows<144>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE},
+                             LinearRows<272>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE});
     __builtin_amdgcn_s_barrier();
     stores_pending = (tm + 1) * BM_ <= M;
   }
+}
+
+// ---------------------------------------------------------------------------------------------- phased variant
+// 256x128 tile, 8 waves, 3-deep ring, same data movement as above, but every K-stage is cut into FOUR barrier-
+// separated phases  R0 | M0 | R1 | M1  (R = LDS-DMA issue + ds_read of one 32-deep k-step, M = its 16 MFMAs) and waves
+// 4-7 run ONE phase behind waves 0-3 (they take one extra barrier up front, waves 0-3 one extra at the end).  Each
+// SIMD hosts one wave of either group, so while one wave multiplies, its partner is in its memory phase, instead of
+// both contending for the matrix pipe and then both waiting on LDS / DMA.
+//   RAW: the DMA of stage f+1 is waited for (own pieces, counted vmcnt) at the END of R1(f); the leading group reads
+//        it in R0(f+1), i.e. after the barrier that the trailing group only passes once ITS wait in R1(f) is done.
+//   WAR: stage f+2 goes to the slot of stage f-1, last read by the trailing group in its R1(f-1), which is over when
+//        the leading group enters R0(f) (one barrier later) and issues the DMA.
+//   Epilogue scratch = the wave's OWN DMA slabs of the released slot, so the partner group's DMA of the next stage
+//        (issued one phase earlier / later) never touches it; no barrier is needed around the epilogue.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bt_phased_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using v8 = typename Vec<T>::v8;
+  constexpr int BM_ = 256, BN = 128, NW = 8, NS = 3;
+  constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_IT = BM_ / 8 / NW, B_IT = BN / 8 / NW, LOADS = A_IT + B_IT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool trail = wave >= NW / 2;
+  const int M = g.M, N = g.N, K = g.K;
+  const T* __restrict__ A = (const T*)g.A;
+  const T* __restrict__ Bt = (const T*)g.Bt;
+
+  const int G = gridDim.x, b = blockIdx.x;
+  const int tilesN = N / BN;
+  const int ntiles = ((M + BM_ - 1) / BM_) * tilesN;
+  const int gq = G >> 3, gr = G & 7, xcd = b & 7;
+  const int b_remap = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (b >> 3);
+  auto tile_of = [&](int round) -> int {
+    const int base = round * G;
+    return base + ((base + G <= ntiles) ? b_remap : b);
+  };
+  const int srow = lane >> 3;
+  const int scol = ((lane & 7) ^ srow) * 8;
+  const T* ap[A_IT];
+  const T* bp[B_IT];
+  auto set_ptrs = [&](int t) {
+    const int m0 = (t / tilesN) * BM_, n0 = (t % tilesN) * BN;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int ar = m0 + (i * NW + wave) * 8 + srow; ar = ar < M ? ar : M - 1;
+      ap[i] = A + (size_t)ar * K + scol;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int br = n0 + (i * NW + wave) * 8 + srow;
+      bp[i] = Bt + (size_t)br * K + scol;
+    }
+  };
+  const int nk = K / BK;
+  int lround = 0, lt = tile_of(0), lkt = 0, lslot = 0;
+  if (lt >= ntiles) return;
+  set_ptrs(lt);
+  auto issue = [&]() -> bool {
+    if (lt >= ntiles) return false;
+    char* base = smem + lslot * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) glds16(ap[i] + lkt * BK, base + (i * NW + wave) * 1024);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) glds16(bp[i] + lkt * BK, base + A_BYTES + (i * NW + wave) * 1024);
+    lslot = lslot + 1 == NS ? 0 : lslot + 1;
+    if (++lkt == nk) {
+      lkt = 0;
+      lt = tile_of(++lround);
+      if (lt < ntiles) set_ptrs(lt);
+    }
+    return true;
+  };
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int a_off = (wm * 64 + fr) * 128;
+  const int b_off = A_BYTES + (wn * 64 + fr) * 128;
+  const int c0 = ((0 + fg) ^ (fr & 7)) * 16;
+  const int c1 = ((4 + fg) ^ (fr & 7)) * 16;
+
+  bool more = issue();
+  more = issue();
+  if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (trail) __builtin_amdgcn_s_barrier();          // the trailing group stays one phase behind from here on
+
+  constexpr int ST_MIN = (EPI == EPI_STORE16 || EPI == EPI_GELU) ? 8 : 16;
+  bool stores_pending = false;
+  int slot = 0;
+  int t = tile_of(0);
+  for (int round = 0; t < ntiles; t = tile_of(++round)) {
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* base = smem + slot * STAGE;
+      v8 af[4], bf[4];
+      // ---- R0: DMA of stage f+2 into the slot released two barriers ago; fragments of k-step 0
+      const bool issued = issue();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { bf[i] = *(const v8*)(base + b_off + i * 2048 + c0); af[i] = *(const v8*)(base + a_off + i * 2048 + c0); }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- M0
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(bf[j], af[i], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- R1: fragments of k-step 1; own pieces of stage f+1 must have landed before the barrier
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { bf[i] = *(const v8*)(base + b_off + i * 2048 + c1); af[i] = *(const v8*)(base + a_off + i * 2048 + c1); }
+      if (issued) {
+        if (stores_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + ST_MIN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      stores_pending = false;
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- M1
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(bf[j], af[i], acc[i][j]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+    const int tm = t / tilesN, tn = t - tm * tilesN;
+    epilogue_store<T, EPI>(g, acc, tm * BM_ + wm * 64, tn * BN + wn * 64, lane,
+                           SlabRows<144>{smem + lslot * STAGE, wave, A_BYTES}, SlabRows<272>{smem + lslot * STAGE, wave, A_BYTES});
+    stores_pending = (tm + 1) * BM_ <= M;
+  }
+  if (!trail) __builtin_amdgcn_s_barrier();         // balance the extra barrier of the trailing group
+}
+
+template <typename T, int EPI>
+static hipError_t launch_phased(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  constexpr int LDS = 3 * (256 + 128) * BK * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_bt_phased_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  const int tiles = ((g.M + 255) / 256) * (g.N / 128);
+  hipExtLaunchKernelGGL((gemm_bt_phased_kernel<T, EPI>), dim3(tiles < cus ? tiles : cus), dim3(512), LDS, s, ea, eb, 0, g);
+  return hipGetLastError();
 }
 
 template <typename T, int EPI, int BM_, int BN_, int NW, int NS>
@@ -339,6 +522,10 @@ static hipError_t launch_t(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipE
   const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
   const long t256 = (long)((g.M + 255) / 256) * (g.N / 256);
   static const int geo = getenv("MVLPT_GEMM_GEO") ? atoi(getenv("MVLPT_GEMM_GEO")) : 2;   // experiment switch (0,1,2)
+  // phased 256x128 variant: measured +3..5 % on long-K GEMMs (MLP down-projection, K = 4d), -4..6 % on K = d
+  static const int phased = getenv("MVLPT_GEMM_PHASED") ? atoi(getenv("MVLPT_GEMM_PHASED")) : 2;   // 0 off, 1 all, 2 long K
+  if (t128 >= 384 && (phased == 1 || (phased == 2 && g.K >= 2048 && !(g.N % 256 == 0 && t256 >= 1024))))
+    return launch_phased<T, EPI>(g, s, ea, eb);
   if (geo >= 2 && g.N % 256 == 0 && t256 >= 1024) return launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
   if (geo >= 1 && t128 >= 384) return launch_geo<T, EPI, 256, 128, 8, 3>(g, 1, s, ea, eb);
   return launch_geo<T, EPI, 128, 128, 4, 2>(g, 2, s, ea, eb);
