@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--method", default="coop", choices=["coop", "vpt", "upt"])
     ap.add_argument("--cut", action="store_true", help="CUT_CONTEXTLEN text length instead of 77")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--trim-eot", action="store_true", help="evaluate the causal text tower only up to max(EOT) (exact; off by default)")
     ap.add_argument("--shard-text", action="store_true", help="class-shard the text tower over the ranks (many-class configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -134,6 +135,7 @@ def main():
     dm = SyntheticDataManager(cfg, args.classes, n_batches, device=dev, seed=1234 + rank)
     trainer = MVLPT(cfg, dm=dm, clip_state_dict=sd)
     trainer.num_batches = 10 ** 9   # no LR-schedule step inside the timed region
+    trainer.model.trim_text_to_eot = args.trim_eot
     if args.shard_text and world > 1:
         trainer.model.enable_class_sharding(rank, world)
     L_text = trainer.model.prompt_learner.tokenized_prompts.shape[1]
@@ -181,7 +183,8 @@ def main():
     if rank == 0:
         B_global = args.batch * world
         ips = B_global * args.steps / elapsed
-        gf_img = algorithmic_gflop_per_image(arch, B_global, args.classes, L_text, n_ctx, n_vpt)
+        L_alg = (trainer.model.prompt_learner.max_eot + 1) if args.trim_eot else L_text   # charge only evaluated positions
+        gf_img = algorithmic_gflop_per_image(arch, B_global, args.classes, L_alg, n_ctx, n_vpt)
         line = {
             "metric": "prompt-tuning images/sec (fwd+bwd), ViT-B/16 bs=256, 1/2/4/8 MI355X",
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -191,6 +194,7 @@ def main():
                                      ("coop", "ViT-B/16", 100, 256) else "variant: ") +
                                     f"MVLPT {args.method} head, {args.arch}, {args.classes} classes, "
                                     f"n_ctx={n_ctx} n_vpt={n_vpt}, text L={L_text}, class token middle"),
+                       "text_positions_evaluated": (trainer.model.prompt_learner.max_eot + 1) if args.trim_eot else L_text,
                        "per_gpu_batch": args.batch, "global_batch": B_global, "parallelism": f"dp{world}",
                        "text_tower": "class-sharded over ranks" if (args.shard_text and world > 1) else "replicated per GPU", "loss": round(loss, 5)},
             "step_mfma_fraction": round(ips / world * gf_img / (MFMA_PEAK_TFLOPS * 1e3), 4),

@@ -269,6 +269,7 @@ class MultitaskVLPromptLearner(nn.Module):
         self.register_buffer("layout", build_prompt_layout(self.name_lens, coop_n_ctx, L, self.class_token_position),
                              persistent=False)
         self.register_buffer("eot", tokenized_prompts.argmax(dim=-1).to(torch.int32), persistent=False)   # :128
+        self.max_eot = int(self.eot.max())
 
     # trainers/mvlpt.py:376-414
     def forward_mvlpt_proj(self, dtype=torch.float):
@@ -330,6 +331,17 @@ def _scatter_class_grads(dtxt: torch.Tensor, lo: int, hi: int, cmax: int, world:
 
 
 # ------------------------------------------------------------------------------------------------ autograd bridge
+def _text_inputs(model, pl):
+    """token_suffix / layout handed to the text tower.  With `trim_text_to_eot` (off by default) only the first
+    max(eot)+1 positions are evaluated: the text transformer is causal (clip/model.py:324-330) and the feature is read
+    at the EOT position (trainers/mvlpt.py:128), so later (padding) positions can influence neither the logits nor
+    any gradient — the same observation the reference's CUT_CONTEXTLEN option is built on (trainers/mvlpt.py:297-305)."""
+    if not model.trim_text_to_eot:
+        return pl.token_suffix, pl.layout
+    L_eff = pl.max_eot + 1
+    return pl.token_suffix[:, :L_eff - 1 - pl.coop_n_ctx], pl.layout[:, :L_eff]
+
+
 class _PromptedClipFn(torch.autograd.Function):
     """CustomCLIP.forward as ONE autograd node: forward and backward are libmvlpt_hip.so calls."""
 
@@ -353,6 +365,7 @@ class _PromptedClipFn(torch.autograd.Function):
         else:
             cached_eval = False
         run_text = not ((coop_emb is None or cached_eval) and model._const_text_features is not None)
+        suffix, layout = _text_inputs(model, pl)
         shard = model._class_shard if (run_text and coop_emb is not None) else None
         side = model._side_stream if (run_text and model.overlap_towers and shard is None) else None
         if shard is not None:
@@ -361,7 +374,7 @@ class _PromptedClipFn(torch.autograd.Function):
             img = eng.image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
             lo, hi, cmax, world = shard
             ctx_loc = coop_emb if coop_emb.dim() == 2 else coop_emb[lo:hi]
-            loc = eng.text_fwd(pl.token_prefix[lo:hi], pl.token_suffix[lo:hi], ctx_loc, pl.layout[lo:hi], pl.eot[lo:hi],
+            loc = eng.text_fwd(pl.token_prefix[lo:hi], suffix[lo:hi], ctx_loc, layout[lo:hi], pl.eot[lo:hi],
                                save_for_bwd=need_txt)
             txt = _gather_class_shards(loc, cmax, world, pl.n_cls)
         elif side is not None:
@@ -370,14 +383,14 @@ class _PromptedClipFn(torch.autograd.Function):
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                txt = eng.text_fwd(pl.token_prefix, pl.token_suffix, coop_emb, pl.layout, pl.eot, save_for_bwd=need_txt)
+                txt = eng.text_fwd(pl.token_prefix, suffix, coop_emb, layout, pl.eot, save_for_bwd=need_txt)
             img = eng.image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
             main.wait_stream(side)
             txt.record_stream(main)
         else:
             img = eng.image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
             if run_text:
-                txt = eng.text_fwd(pl.token_prefix, pl.token_suffix, coop_emb, pl.layout, pl.eot, save_for_bwd=need_txt)
+                txt = eng.text_fwd(pl.token_prefix, suffix, coop_emb, layout, pl.eot, save_for_bwd=need_txt)
         if not run_text:
             txt = model._const_text_features
         elif coop_emb is None:
@@ -451,6 +464,7 @@ class CustomCLIP(nn.Module):
         self.overlap_towers = True
         self._class_shard = None
         self._eval_text_cache = None
+        self.trim_text_to_eot = False
         self._side_stream = torch.cuda.Stream(device=clip_model.device) if torch.cuda.is_available() else None
         self.multi_task_label_pertask = cfg.DATASET.MULTITASK_LABEL_PERTASK
         if self.multi_task_label_pertask:

@@ -173,6 +173,21 @@ def test_full_size_case_fp16(arch_name, name):
     print(f"{name}: logits {err:.2e} grads {max(worst.values()):.2e}")
 
 
+def test_trim_to_eot_is_exact(tiny_clip_fp16):
+    """Evaluating the causal text tower only up to max(EOT) changes neither logits nor gradients (beyond fp rounding)."""
+    case = load_npz("tiny_coop_middle")
+    outs = []
+    for trim in (False, True):
+        model = build_model(case, tiny_clip_fp16, 32, t(case["token_prefix"]), t(case["token_suffix"]))
+        model.trim_text_to_eot = trim
+        dev = tiny_clip_fp16.device
+        logits = model(t(case["image"]).to(dev))
+        model.cross_entropy(logits, t(case["label"]).to(dev)).backward()
+        outs.append((logits.detach().cpu(), model.prompt_learner.ctx.grad.cpu().clone()))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-5
+    assert float((outs[0][1] - outs[1][1]).abs().max()) / float(outs[0][1].abs().max()) < 1e-4
+
+
 def test_no_cpu_path():
     from mvlpt_amd import engine
     with pytest.raises(RuntimeError):
