@@ -113,6 +113,8 @@ typedef struct MvlptKernelStat {
   double ms;    /* sum of event-timed launch durations */
   double flops; /* algorithmic FLOPs summed over launches (2*M*N*K for GEMM, 4*L*L*64 per head for attention) */
   double bytes; /* algorithmic HBM bytes summed over launches */
+  double busy_ms; /* length of the UNION of the launch intervals: equals `ms` when launches never overlap; smaller
+                     when the same kernel runs concurrently on two streams (image and text tower) */
 } MvlptKernelStat;
 /* all_kernels == 0: only the dominant kernel (gemm_bt) is timed, through its own dispatch timestamps (no marker
  * packets on the stream); != 0: every kernel class is bracketed by marker events (adds ~1.5 us per event). */

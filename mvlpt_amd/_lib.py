@@ -25,7 +25,7 @@ class MvlptArch(C.Structure):
 
 class MvlptKernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("ms", C.c_double),
-                ("flops", C.c_double), ("bytes", C.c_double)]
+                ("flops", C.c_double), ("bytes", C.c_double), ("busy_ms", C.c_double)]
 
 
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float

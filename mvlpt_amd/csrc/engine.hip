@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -722,11 +723,25 @@ int mvlpt_profile_end(void* h, MvlptKernelStat* stats, int max_stats) {
   E->prof_on = false;
   MvlptKernelStat acc[PC_COUNT];
   for (int i = 0; i < PC_COUNT; ++i) { memset(&acc[i], 0, sizeof(acc[i])); snprintf(acc[i].name, sizeof(acc[i].name), "%s", kProfNames[i]); }
+  std::vector<std::pair<float, float>> iv[PC_COUNT];     // [start, end] in ms relative to the first recorded event
+  hipEvent_t ref = E->prof.empty() ? nullptr : E->prof.front().a;
   for (const ProfRec& r : E->prof) {
     if (hipEventSynchronize(r.b) != hipSuccess) continue;
-    float ms = 0.f;
+    float ms = 0.f, t0 = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
     acc[r.cls].launches += 1; acc[r.cls].ms += ms; acc[r.cls].flops += r.flops; acc[r.cls].bytes += r.bytes;
+    if (r.a == ref || hipEventElapsedTime(&t0, ref, r.a) == hipSuccess) iv[r.cls].push_back({t0, t0 + ms});
+  }
+  for (int c = 0; c < PC_COUNT; ++c) {                    // union of the intervals per class
+    std::sort(iv[c].begin(), iv[c].end());
+    double busy = 0.0; float cs = 0.f, ce = -1.f;
+    for (auto& p : iv[c]) {
+      if (ce < 0.f) { cs = p.first; ce = p.second; }
+      else if (p.first > ce) { busy += ce - cs; cs = p.first; ce = p.second; }
+      else if (p.second > ce) ce = p.second;
+    }
+    if (ce >= 0.f) busy += ce - cs;
+    acc[c].busy_ms = busy;
   }
   int n = 0;
   for (int i = 0; i < PC_COUNT && n < max_stats; ++i) if (acc[i].launches) stats[n++] = acc[i];

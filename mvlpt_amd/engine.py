@@ -203,7 +203,7 @@ class Engine:
         n = lib.mvlpt_profile_end(self.h, arr, 16)
         if n < 0:
             raise RuntimeError("profile_end failed")
-        return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes)
+        return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes, busy_ms=arr[i].busy_ms)
                 for i in range(n)}
 
 
