@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--cut", action="store_true", help="CUT_CONTEXTLEN text length instead of 77")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--trim-eot", action="store_true", help="evaluate the causal text tower only up to max(EOT) (exact; off by default)")
+    ap.add_argument("--no-step-pipelining", action="store_true",
+                    help="do not compute the next batch's image features underneath the current backward")
     ap.add_argument("--shard-text", action="store_true", help="class-shard the text tower over the ranks (many-class configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -141,9 +143,12 @@ def main():
     L_text = trainer.model.prompt_learner.tokenized_prompts.shape[1]
     eng = trainer.model.engine
 
+    pipeline = not args.no_step_pipelining
+
     def step(i):
         trainer.batch_idx = i
-        return trainer.forward_backward(dm.train_loader_x[i % n_batches])
+        nxt = dm.train_loader_x[(i + 1) % n_batches] if pipeline else None
+        return trainer.forward_backward(dm.train_loader_x[i % n_batches], next_batch=nxt)
 
     for i in range(args.warmup):
         out = step(i)
@@ -195,6 +200,7 @@ def main():
                                     f"MVLPT {args.method} head, {args.arch}, {args.classes} classes, "
                                     f"n_ctx={n_ctx} n_vpt={n_vpt}, text L={L_text}, class token middle"),
                        "text_positions_evaluated": (trainer.model.prompt_learner.max_eot + 1) if args.trim_eot else L_text,
+                       "step_pipelining": bool(pipeline and n_vpt == 0),
                        "per_gpu_batch": args.batch, "global_batch": B_global, "parallelism": f"dp{world}",
                        "text_tower": "class-sharded over ranks" if (args.shard_text and world > 1) else "replicated per GPU", "loss": round(loss, 5)},
             "step_mfma_fraction": round(ips / world * gf_img / (MFMA_PEAK_TFLOPS * 1e3), 4),

@@ -514,9 +514,34 @@ static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hi
   return hipGetLastError();
 }
 
+static int num_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// rows [m_lo, m_lo + rows) of the problem as a GEMM of its own (all operands are row-major with leading dimension
+// K or N, so a row range is a contiguous sub-problem)
+template <int EPI>
+static GemmArgs row_slice(const GemmArgs& g, int m_lo, int rows) {
+  GemmArgs r = g;
+  const size_t ok = (size_t)m_lo * g.K, on = (size_t)m_lo * g.N;
+  constexpr size_t OB = (EPI == EPI_RESID32 || EPI == EPI_STORE32) ? 4 : 2;
+  r.A = (const char*)g.A + ok * 2;
+  r.M = rows;
+  r.out = (char*)g.out + on * OB;
+  if (g.out2) r.out2 = (char*)g.out2 + on * 2;
+  if (g.aux) r.aux = (const char*)g.aux + on * 2;
+  if (g.resid) r.resid = g.resid + on;
+  return r;
+}
+
 template <typename T, int EPI>
-static hipError_t launch_t(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
-  // big geometry when its tiles fill the chip at least ~1.5 times; otherwise the 128x128 geometry
+static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb, int* tile_m, int* tile_n) {
   // geometry by tile count: 256x256 (128x64 wave tiles, least LDS-DMA / LDS-read traffic per FLOP) needs >= 4 full
   // rounds of 256 resident workgroups to amortise its tail; 256x128 needs >= 1.5 rounds; otherwise 128x128.
   const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
@@ -524,11 +549,50 @@ static hipError_t launch_t(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipE
   static const int geo = getenv("MVLPT_GEMM_GEO") ? atoi(getenv("MVLPT_GEMM_GEO")) : 2;   // experiment switch (0,1,2)
   // phased 256x128 variant: measured +3..5 % on long-K GEMMs (MLP down-projection, K = 4d), -4..6 % on K = d
   static const int phased = getenv("MVLPT_GEMM_PHASED") ? atoi(getenv("MVLPT_GEMM_PHASED")) : 2;   // 0 off, 1 all, 2 long K
-  if (t128 >= 384 && (phased == 1 || (phased == 2 && g.K >= 2048 && !(g.N % 256 == 0 && t256 >= 1024))))
-    return launch_phased<T, EPI>(g, s, ea, eb);
-  if (geo >= 2 && g.N % 256 == 0 && t256 >= 1024) return launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
-  if (geo >= 1 && t128 >= 384) return launch_geo<T, EPI, 256, 128, 8, 3>(g, 1, s, ea, eb);
-  return launch_geo<T, EPI, 128, 128, 4, 2>(g, 2, s, ea, eb);
+  if (t128 >= 384 && (phased == 1 || (phased == 2 && g.K >= 2048 && !(g.N % 256 == 0 && t256 >= 1024)))) {
+    *tile_m = 256; *tile_n = 128;
+    return ea == (hipEvent_t)-1 ? hipSuccess : launch_phased<T, EPI>(g, s, ea, eb);
+  }
+  if (geo >= 2 && g.N % 256 == 0 && t256 >= 1024) {
+    *tile_m = 256; *tile_n = 256;
+    return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
+  }
+  if (geo >= 1 && t128 >= 384) {
+    *tile_m = 256; *tile_n = 128;
+    return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 128, 8, 3>(g, 1, s, ea, eb);
+  }
+  *tile_m = 128; *tile_n = 128;
+  return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 128, 128, 4, 2>(g, 2, s, ea, eb);
+}
+
+template <typename T, int EPI>
+static hipError_t launch_t(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  // Tail splitting (experiment, off by default).  The persistent grid runs rounds of `cus` big tiles; a ragged last round (e.g. 9.23 rounds for the
+  // MLP up-projection) leaves most CUs idle for a full tile time.  When the last round is less than ~70 % full, the
+  // rows of whole rounds go to the big geometry and the remaining rows are a second, small-tile launch (128x128,
+  // two workgroups per CU), which finishes in about half a big-tile time.
+  int bm = 0, bn = 0;
+  (void)launch_one<T, EPI>(g, s, (hipEvent_t)-1, nullptr, &bm, &bn);      // query the geometry only
+  static const int split = getenv("MVLPT_GEMM_TAILSPLIT") ? atoi(getenv("MVLPT_GEMM_TAILSPLIT")) : 0;   // measured: +2 % / -8 % by shape -> off
+  if (split && bm == 256) {
+    const int cus = num_cus();
+    const long tn = g.N / bn, tm = (g.M + bm - 1) / bm, tiles = tm * tn;
+    const long full = tiles / cus;
+    const double frac = (double)(tiles - full * cus) / cus;
+    if (full >= 2 && frac > 0.02 && frac < 0.7) {
+      const long tm_main = full * cus / tn;                     // M tiles that fit the whole rounds
+      const int m_main = (int)(tm_main * bm);
+      if (m_main > 0 && m_main < g.M) {
+        const GemmArgs a = row_slice<EPI>(g, 0, m_main), b = row_slice<EPI>(g, m_main, g.M - m_main);
+        int x, y;
+        hipError_t e = launch_one<T, EPI>(a, s, ea, nullptr, &x, &y);
+        if (e != hipSuccess) return e;
+        return launch_geo<T, EPI, 128, 128, 4, 2>(b, 2, s, nullptr, eb);
+      }
+    }
+  }
+  int x, y;
+  return launch_one<T, EPI>(g, s, ea, eb, &x, &y);
 }
 
 template <typename T>

@@ -366,12 +366,21 @@ class _PromptedClipFn(torch.autograd.Function):
             cached_eval = False
         run_text = not ((coop_emb is None or cached_eval) and model._const_text_features is not None)
         suffix, layout = _text_inputs(model, pl)
+        pre = model._prefetched
+        model._prefetched = None
+        if pre is not None and vpt_emb is None and pre[:3] == (image.data_ptr(), tuple(image.shape), image._version):
+            def image_fwd(*_a, **_k):                 # features of this very tensor were computed ahead of time
+                torch.cuda.current_stream().wait_event(pre[4])
+                pre[3].record_stream(torch.cuda.current_stream())
+                return pre[3]
+        else:
+            image_fwd = eng.image_fwd
         shard = model._class_shard if (run_text and coop_emb is not None) else None
         side = model._side_stream if (run_text and model.overlap_towers and shard is None) else None
         if shard is not None:
             # Class-sharded text tower (collective 2): this rank encodes classes [lo, hi) only, the
             # features are all-gathered; the backward reduce-scatters d(txt) back to the owners.
-            img = eng.image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
+            img = image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
             lo, hi, cmax, world = shard
             ctx_loc = coop_emb if coop_emb.dim() == 2 else coop_emb[lo:hi]
             loc = eng.text_fwd(pl.token_prefix[lo:hi], suffix[lo:hi], ctx_loc, layout[lo:hi], pl.eot[lo:hi],
@@ -384,11 +393,11 @@ class _PromptedClipFn(torch.autograd.Function):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 txt = eng.text_fwd(pl.token_prefix, suffix, coop_emb, layout, pl.eot, save_for_bwd=need_txt)
-            img = eng.image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
+            img = image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
             main.wait_stream(side)
             txt.record_stream(main)
         else:
-            img = eng.image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
+            img = image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
             if run_text:
                 txt = eng.text_fwd(pl.token_prefix, suffix, coop_emb, layout, pl.eot, save_for_bwd=need_txt)
         if not run_text:
@@ -465,6 +474,8 @@ class CustomCLIP(nn.Module):
         self._class_shard = None
         self._eval_text_cache = None
         self.trim_text_to_eot = False
+        self._prefetch_stream = None
+        self._prefetched = None
         self._side_stream = torch.cuda.Stream(device=clip_model.device) if torch.cuda.is_available() else None
         self.multi_task_label_pertask = cfg.DATASET.MULTITASK_LABEL_PERTASK
         if self.multi_task_label_pertask:
@@ -490,6 +501,26 @@ class CustomCLIP(nn.Module):
         if hi <= lo:
             raise ValueError("more ranks than classes: class sharding needs at least one class per rank")
         self._class_shard = (lo, hi, cmax, world)
+
+    def prefetch_image_features(self, image) -> bool:
+        """Software pipelining across steps: with no visual prompts the image tower is a pure function of the image
+        (frozen weights, trainers/mvlpt.py:855-858), so the features of the NEXT batch can be computed on a third
+        HIP stream while the current step's text-tower backward (small launches that cannot fill the chip) and
+        optimizer run.  `forward(image)` picks the result up when it is called with the same tensor."""
+        pl = self.prompt_learner
+        if pl.vpt_embeddings is not None or self._side_stream is None:
+            return False
+        main = torch.cuda.current_stream()
+        if self._prefetch_stream is None:
+            self._prefetch_stream = torch.cuda.Stream(device=self.clip_model.device)
+        st = self._prefetch_stream
+        st.wait_stream(main)                       # the tower workspace of the previous image forward is free
+        with torch.cuda.stream(st):
+            feat = self.engine.image_fwd(image, None, None, save_for_bwd=False)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self._prefetched = (image.data_ptr(), tuple(image.shape), image._version, feat, ev)
+        return True
 
     def forward(self, image, task=None):
         coop_emb, vpt_emb, vpt_emb_deep = self.prompt_learner.forward_mvlpt_proj(self.dtype)

@@ -269,13 +269,17 @@ class MVLPT(TrainerX):
         self.register_model("prompt_learner", self.model.prompt_learner, self.optim, self.sched)
         self.scaler = None    # the HIP backward scales its 16-bit activation gradients internally
 
-    def forward_backward(self, batch):
+    def forward_backward(self, batch, next_batch=None):
+        """trainers/mvlpt.py:910-951.  `next_batch` (optional, not in the reference): lets the image features of the
+        following step be computed underneath this step's backward when the method has no visual prompts."""
         image, label, tasks_ = self.parse_batch_train(batch)
         if len(label.shape) > 1 and label.shape[-1] > 1:                # :914-916
             label = label.float()
             label = label / label.sum(dim=-1, keepdim=True)
         output = self.model(image, task=tasks_)
         loss = self.model.cross_entropy(output, label)                  # F.cross_entropy (:931) as a HIP kernel
+        if next_batch is not None:
+            self.model.prefetch_image_features(self.parse_batch_train(next_batch)[0])
         self.model_backward_and_update(loss)
         # device tensors: no .item() sync inside the step (the reference syncs twice per step, :941-942)
         loss_summary = {"loss": loss.detach(), "acc": self.model.last_ncorrect[0] * (100.0 / output.shape[0])}

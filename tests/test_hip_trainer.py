@@ -73,3 +73,22 @@ def test_eval_accuracy_and_text_cache(tmp_path):
     tr.forward_backward(tr.train_loader_x[0])                    # SGD step bumps the parameter versions
     tr.test()
     assert model._eval_text_cache[0] != ver0
+
+
+def test_step_pipelining_is_transparent(tmp_path):
+    """Prefetching the next batch's image features under the backward must not change any result."""
+    import copy
+    runs = []
+    for pipe in (False, True):
+        torch.manual_seed(0)                      # same prompt initialisation in both runs
+        tr = make_trainer(tmp_path, "coop")
+        tr.set_model_mode("train")
+        tr.num_batches = 10 ** 9
+        losses = []
+        for i in range(6):
+            tr.batch_idx = i
+            nxt = tr.train_loader_x[(i + 1) % 4] if pipe else None
+            losses.append(float(tr.forward_backward(tr.train_loader_x[i % 4], next_batch=nxt)["loss"]))
+        runs.append((losses, tr.model.prompt_learner.ctx.detach().cpu().clone()))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
