@@ -149,7 +149,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
 // next tile are in flight while the current tile finishes and its epilogue is stored), so the short-K GEMMs of
 // this path (K = 768 / 512) do not pay a load bubble per tile.
 template <typename T, int EPI, int BM_, int BN_, int NW, int NS>
-__global__ __launch_bounds__(NW * 64, 2) void gemm_bt_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using v8 = typename Vec<T>::v8;
   constexpr int BN = BN_;
@@ -157,6 +157,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bt_kernel(GemmArgs g) {
   constexpr int WMF = BM_ / WCM / 16;                 // 16-row A fragments per wave (4: 64x64 wave tile, 8: 128x64)
   constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int A_IT = BM_ / 8 / NW, B_IT = BN / 8 / NW, LOADS = A_IT + B_IT;
+  constexpr int ST_MIN_ = (WMF / 4) * ((EPI == EPI_STORE16 || EPI == EPI_GELU) ? 8 : 16);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -229,20 +230,21 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bt_kernel(GemmArgs g) {
   const int c0 = ((0 + fg) ^ (fr & 7)) * 16;        // k-step 0 chunk
   const int c1 = ((4 + fg) ^ (fr & 7)) * 16;        // k-step 1 chunk
 
-  // prologue: fill NS-1 ring slots, wait for the first
-  bool more = issue();
-  if constexpr (NS == 3) {
-    more = issue();
-    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  // prologue: fill NS-1 ring slots, wait for the first.  `n_issued` K-stages have been requested so far; a wait that
+  // must guarantee stage j may leave the n_issued - (j + 1) younger stages in flight (vmcnt retires in order).
+  int n_issued = 0, n_done = 0;
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i) n_issued += issue() ? 1 : 0;
+  auto wait_stage = [&](int younger, bool skip_stores) {
+    if (younger >= 2 && NS >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+    else if (younger >= 1 && NS >= 3) {
+      if (skip_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + ST_MIN_) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  wait_stage(n_issued - 1, false);
   __builtin_amdgcn_s_barrier();
 
-  // lower bound of the global STORE instructions one full-tile epilogue issues per wave (8 x 16 B for 16-bit outputs
-  // of a 64x64 block, 16 for fp32-staged ones); used only when every row of the tile exists (no masked-off stores)
-  constexpr int ST_MIN = (WMF / 4) * ((EPI == EPI_STORE16 || EPI == EPI_GELU) ? 8 : 16);
   bool stores_pending = false;
   int slot = 0;
   int t = tile_of(0);
@@ -298,17 +300,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bt_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
       }
       if (!dma_first) issued = issue();
-      // the NEXT stage must have landed (own loads) before the barrier; the one just issued may stay in flight.
+      n_issued += issued ? 1 : 0;
+      // the NEXT stage (n_done + 1) must have landed (own loads) before the barrier; younger ones may stay in flight.
       // vmcnt retires in order and counts stores: right after an epilogue the youngest operations are its ST_MIN
       // global stores followed by the DMA just issued, so allowing ST_MIN + LOADS operations in flight still
-      // guarantees the older DMA has landed without making the wave wait for its own output stores.
-      if (NS == 3 && issued) {
-        if (stores_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + ST_MIN) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      // guarantees the older DMA has landed without making the wave wait for its own output stores (NS == 3 only).
+      wait_stage(n_issued - (n_done + 2), stores_pending && NS == 3 && issued);
       stores_pending = false;
+      ++n_done;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       slot = slot + 1 == NS ? 0 : slot + 1;
@@ -560,6 +559,14 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   if (geo >= 1 && t128 >= 384) {
     *tile_m = 256; *tile_n = 128;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 128, 8, 3>(g, 1, s, ea, eb);
+  }
+  // small problems (text tower: M = C*L ~ 7.7k rows) put at most one workgroup on a CU, so nothing hides the
+  // LDS-DMA latency of a 2-deep ring: use a 4-deep ring (128 KiB, three K-stages in flight) instead
+  static const int deep = getenv("MVLPT_GEMM_DEEP") ? atoi(getenv("MVLPT_GEMM_DEEP")) : 1;
+  const long t_small = (long)((g.M + 127) / 128) * (g.N / 128);
+  if (deep && t_small <= num_cus()) {
+    *tile_m = 128; *tile_n = 128;
+    return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 128, 128, 4, 4>(g, 1, s, ea, eb);
   }
   *tile_m = 128; *tile_n = 128;
   return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 128, 128, 4, 2>(g, 2, s, ea, eb);
