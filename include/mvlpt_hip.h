@@ -119,6 +119,8 @@ typedef struct MvlptKernelStat {
 /* all_kernels == 0: only the dominant kernel (gemm_bt) is timed, through its own dispatch timestamps (no marker
  * packets on the stream); != 0: every kernel class is bracketed by marker events (adds ~1.5 us per event). */
 int mvlpt_profile_begin(void* handle, int all_kernels);
+/* paused != 0: launches are not timed until resumed (bench.py samples every 4th step to keep the overhead ~1 %) */
+int mvlpt_profile_pause(void* handle, int paused);
 /* synchronises the recorded events, fills up to `max_stats` entries, returns the number written (or <0) */
 int mvlpt_profile_end(void* handle, MvlptKernelStat* stats, int max_stats);
 

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mvlpt_op_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvlpt_op_cast": (_i, [_i, _vp, _vp, C.c_int64, _vp]),
     "mvlpt_profile_begin": (_i, [_vp, _i]),
+    "mvlpt_profile_pause": (_i, [_vp, _i]),
     "mvlpt_profile_end": (_i, [_vp, C.POINTER(MvlptKernelStat), _i]),
 }
 

@@ -717,6 +717,12 @@ int mvlpt_profile_begin(void* h, int all_kernels) {
   E->prof.clear(); E->ev_used = 0; E->prof_on = true; E->prof_all = all_kernels != 0;
   return 0;
 }
+int mvlpt_profile_pause(void* h, int paused) {
+  Engine* E = (Engine*)h;
+  if (!E) return MVLPT_ERR_ARG;
+  E->prof_on = !paused;
+  return 0;
+}
 int mvlpt_profile_end(void* h, MvlptKernelStat* stats, int max_stats) {
   Engine* E = (Engine*)h;
   if (!E || !stats || max_stats <= 0) return MVLPT_ERR_ARG;

@@ -562,7 +562,8 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   }
   // small problems (text tower: M = C*L ~ 7.7k rows) put at most one workgroup on a CU, so nothing hides the
   // LDS-DMA latency of a 2-deep ring: use a 4-deep ring (128 KiB, three K-stages in flight) instead
-  static const int deep = getenv("MVLPT_GEMM_DEEP") ? atoi(getenv("MVLPT_GEMM_DEEP")) : 1;
+  static const int deep = getenv("MVLPT_GEMM_DEEP") ? atoi(getenv("MVLPT_GEMM_DEEP")) : 0;   // text tower alone -7 %, but its 128 KiB
+  // workgroups can no longer share a CU with the image tower kernels they overlap with: whole step +1.4 % -> off
   const long t_small = (long)((g.M + 127) / 128) * (g.N / 128);
   if (deep && t_small <= num_cus()) {
     *tile_m = 128; *tile_n = 128;

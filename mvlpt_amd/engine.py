@@ -198,6 +198,9 @@ class Engine:
     def profile_begin(self, all_kernels: bool = False):
         _lib.check(lib.mvlpt_profile_begin(self.h, int(all_kernels)), self.h, "profile_begin")
 
+    def profile_pause(self, paused: bool):
+        _lib.check(lib.mvlpt_profile_pause(self.h, int(paused)), self.h, "profile_pause")
+
     def profile_end(self) -> Dict[str, dict]:
         arr = (_lib.MvlptKernelStat * 16)()
         n = lib.mvlpt_profile_end(self.h, arr, 16)
