@@ -69,6 +69,9 @@ struct AttnBwdArgs {
 };
 hipError_t launch_attn_bwd(int dtype, const AttnBwdArgs& a, hipStream_t s);
 int attn_max_len();
+// streaming variants (attention_stream.hip): any L, 32 KiB LDS ring; launch_attn_* picks between the two families
+hipError_t launch_attn_fwd_stream(int dtype, const AttnArgs& a, hipStream_t s);
+hipError_t launch_attn_bwd_stream(int dtype, const AttnBwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- glue
 hipError_t launch_cast_f32_to16(int dtype, const float* in, void* out, size_t n, const float* scale_dev, hipStream_t s);

@@ -13,7 +13,8 @@ def timeit(fn, iters=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 
-for (N, L, H, causal) in [(256, 197, 12, False), (256, 205, 12, False), (256, 50, 12, False), (100, 77, 8, True), (1000, 77, 8, True)]:
+for (N, L, H, causal) in [(256, 197, 12, False), (256, 205, 12, False), (256, 50, 12, False), (100, 77, 8, True), (1000, 77, 8, True),
+                          (128, 261, 16, False), (128, 581, 16, False)]:
     d = H * 64
     qkv = torch.randn(N * L, 3 * d, device="cuda").half()
     out, lse = E.op_attention_fwd(qkv, N, L, H, causal)
