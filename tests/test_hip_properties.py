@@ -1,0 +1,184 @@
+"""Size-independent properties of the HIP path at BASELINE.json's FULL headline size (ViT-B/16, batch 256, 100 classes,
+CoOp-16 `middle`, text L = 77; plus VPT-deep / UPT at batch 64), where the CPU oracle would take minutes per step:
+
+  * rows are independent: permuting the images permutes the logits rows, permuting the classes permutes the columns,
+    a batch evaluated in two halves equals the whole batch — BIT-EXACT (same kernels, same K order per output row);
+  * the backward is linear in d(logits): 2x the loss gives exactly 2x every prompt gradient (device-side power-of-two
+    gradient scaling must be transparent), and a zero upstream gradient gives exactly zero;
+  * cosine logits are bounded by exp(logit_scale); the multiplicative task mask zeroes out-of-task columns exactly and
+    leaves in-task columns untouched (trainers/mvlpt.py:575-581);
+  * mean cross-entropy of B copies of one image equals the single-image loss and gradient (tolerance: fp32 reduction
+    order over the batch only);
+  * one plain-SGD step along the HIP gradient lowers the HIP loss (the gradient is a descent direction)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(method="coop", C=100, n_ctx=16, n_vpt=8, arch_name="ViT-B/16", tasks=None, seed=0):
+    from mvlpt_amd.config import get_cfg_default
+    from mvlpt_amd.model import CustomCLIP, FrozenCLIP
+    from mvlpt_amd.weights import ARCHS, make_state_dict
+    arch = ARCHS[arch_name]
+    sd = make_state_dict(arch, seed=3)
+    cfg = get_cfg_default()
+    cfg.INPUT.SIZE = (arch.image_resolution, arch.image_resolution)
+    T = cfg.TRAINER.MVLPT
+    T.COOP.N_CTX = n_ctx if method in ("coop", "upt") else 0
+    T.COOP.CLASS_TOKEN_POSITION = "middle"
+    T.VPT.N_CTX = n_vpt if method in ("vpt", "upt") else 0
+    T.VPT.DEEP = True
+    T.PROJECT_DIM = 128 if method == "upt" else -1
+    T.PROJECT_METHOD = "transformer" if method == "upt" else "identity"
+    dm = None
+    if tasks:
+        cfg.DATASET.MULTITASK_LABEL_PERTASK = True
+
+        class DM:
+            _num_classes = C
+            _task_names = [f"t{i}" for i in range(len(tasks))]
+            _labelmap = {f"t{i}": list(range(c)) for i, c in enumerate(tasks)}
+        dm = DM()
+    torch.manual_seed(seed)
+    names = [f"class number {i}" if i % 3 else f"c{i}" for i in range(C)]
+    model = CustomCLIP(cfg, names, FrozenCLIP(sd, "fp16"), dm=dm).cuda()
+    return arch, model
+
+
+def _images(arch, B, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, 3, arch.image_resolution, arch.image_resolution, generator=g).cuda()
+
+
+def _grads(model):
+    return {k: p.grad.detach().clone() for k, p in model.prompt_learner.named_parameters() if p.grad is not None}
+
+
+@pytest.fixture(scope="module")
+def headline():
+    return _model("coop", C=100, n_ctx=16)
+
+
+def test_image_rows_are_independent_at_headline_size(headline):
+    arch, model = headline
+    B = 256
+    x = _images(arch, B)
+    with torch.no_grad():
+        full = model(x)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).cuda()
+        assert torch.equal(model(x[perm]), full[perm]), "permuting the images must permute the logits rows bit-exactly"
+        halves = torch.cat([model(x[:128].contiguous()), model(x[128:].contiguous())])
+        assert torch.equal(halves, full), "a batch evaluated in two halves must equal the whole batch bit-exactly"
+    assert full.shape == (B, 100) and torch.isfinite(full).all()
+    bound = math.exp(math.log(1 / 0.07)) * (1 + 1e-5)
+    assert float(full.abs().max()) <= bound, "cosine logits are bounded by exp(logit_scale)"
+
+
+def test_class_rows_are_independent_at_headline_size():
+    arch, m1 = _model("coop", C=100)
+    x = _images(arch, 32)
+    perm = torch.randperm(100, generator=torch.Generator().manual_seed(7))
+    pl = m1.prompt_learner
+    # second model: same prompts, classes in permuted order
+    _, m2 = _model("coop", C=100)
+    pl2 = m2.prompt_learner
+    with torch.no_grad():
+        pl2.ctx.copy_(pl.ctx)
+        pl2.token_prefix.copy_(pl.token_prefix[perm.to(pl.token_prefix.device)])
+        pl2.token_suffix.copy_(pl.token_suffix[perm.to(pl.token_suffix.device)])
+        pl2.layout.copy_(pl.layout[perm.to(pl.layout.device)])
+        pl2.eot.copy_(pl.eot[perm.to(pl.eot.device)])
+        pl2.tokenized_prompts.copy_(pl.tokenized_prompts[perm.to(pl.tokenized_prompts.device)])
+        a, b = m1(x), m2(x)
+    assert torch.equal(a[:, perm.cuda()], b), "permuting the classes must permute the logits columns bit-exactly"
+
+
+@pytest.mark.parametrize("method,B", [("coop", 256), ("vpt", 64), ("upt", 64)])
+def test_backward_is_linear_and_scale_transparent(method, B):
+    arch, model = _model(method, C=100, n_ctx=16 if method == "coop" else 4, n_vpt=8 if method == "vpt" else 4)
+    x = _images(arch, B)
+    y = torch.randint(0, 100, (B,), generator=torch.Generator().manual_seed(2)).cuda()
+
+    def grads(scale):
+        model.zero_grad(set_to_none=True)
+        loss = model.cross_entropy(model(x), y) * scale
+        loss.backward()
+        return float(loss.detach()), _grads(model)
+
+    l1, g1 = grads(1.0)
+    l4, g4 = grads(4.0)
+    lz, gz = grads(0.0)
+    assert g1 and set(g1) == set(g4)
+    direct = [k for k in g1 if not k.startswith("mvlpt_proj")] if method != "upt" else []
+    for k in g1:
+        assert torch.isfinite(g1[k]).all() and float(g1[k].abs().max()) > 0, k
+        if k in direct:      # straight out of the HIP backward: power-of-two scaling must be exact
+            assert torch.equal(g4[k], 4.0 * g1[k]), f"{k}: 4x loss must give exactly 4x gradient"
+        else:                # UPT: passes through torch autograd of the projection (fp32 GEMM reassociation)
+            assert float((g4[k] - 4.0 * g1[k]).abs().max()) <= 1e-5 * float(g4[k].abs().max()), k
+        assert float(gz[k].abs().max()) == 0.0, f"{k}: zero upstream gradient must give zero"
+    assert abs(l4 - 4 * l1) <= 1e-5 * abs(l4)
+
+
+def test_task_mask_zeroes_out_of_task_columns_exactly():
+    tasks = [40, 35, 25]
+    arch, model = _model("coop", C=100, tasks=tasks)
+    _, unmasked = _model("coop", C=100)        # same seed -> same context vectors; no per-task label space
+    assert torch.equal(unmasked.prompt_learner.ctx, model.prompt_learner.ctx)
+    B = 96
+    x = _images(arch, B)
+    task = torch.randint(0, 3, (B,), generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        masked = model(x, task=task)
+        plain = unmasked(x)
+    lo = torch.tensor([0, 40, 75])[task]
+    hi = torch.tensor([40, 75, 100])[task]
+    cols = torch.arange(100).view(1, -1)
+    inside = ((cols >= lo.view(-1, 1)) & (cols < hi.view(-1, 1))).cuda()
+    assert torch.equal(masked[inside], plain[inside])
+    assert float(masked[~inside].abs().max()) == 0.0, "mask is multiplicative 0/1: out-of-task logits are exactly 0"
+
+
+def test_mean_loss_over_copies_equals_single_image():
+    arch, model = _model("vpt", C=100, n_vpt=8)
+    x1 = _images(arch, 1)
+    y1 = torch.tensor([17]).cuda()
+
+    def run(x, y):
+        model.zero_grad(set_to_none=True)
+        loss = model.cross_entropy(model(x), y)
+        loss.backward()
+        return float(loss.detach()), _grads(model)
+
+    l1, g1 = run(x1, y1)
+    l8, g8 = run(x1.expand(64, -1, -1, -1).contiguous(), y1.expand(64).contiguous())
+    assert abs(l1 - l8) <= 1e-6 * max(1.0, abs(l1))
+    for k in g1:
+        # 64 identical per-image gradients of weight 1/64 each: only the fp32 summation order and the 16-bit
+        # rounding of the (64x smaller) upstream gradient differ
+        assert float((g1[k] - g8[k]).abs().max()) <= 2e-3 * float(g1[k].abs().max()), k
+
+
+@pytest.mark.parametrize("method", ["coop", "vpt"])
+def test_gradient_is_a_descent_direction_at_full_size(method):
+    arch, model = _model(method, C=100)
+    B = 128
+    x = _images(arch, B)
+    y = torch.randint(0, 100, (B,), generator=torch.Generator().manual_seed(4)).cuda()
+    params = [p for p in model.prompt_learner.parameters() if p.requires_grad]
+    loss0 = model.cross_entropy(model(x), y)
+    loss0.backward()
+    gnorm2 = sum(float((p.grad ** 2).sum()) for p in params)
+    assert gnorm2 > 0
+    step = 0.05 / math.sqrt(gnorm2)          # small normalised step
+    with torch.no_grad():
+        for p in params:
+            p.add_(p.grad, alpha=-step)
+        loss1 = model.cross_entropy(model(x), y)
+    predicted = step * gnorm2
+    drop = float(loss0.detach()) - float(loss1)
+    assert drop > 0, f"loss did not go down: {float(loss0):.6f} -> {float(loss1):.6f}"
+    assert 0.5 * predicted < drop < 1.5 * predicted, f"first-order prediction {predicted:.3e} vs actual drop {drop:.3e}"
