@@ -193,7 +193,7 @@ class SyntheticDataManager:
     optional task ids with labels drawn inside the task's class range."""
 
     def __init__(self, cfg, num_classes: int, steps_per_epoch: int, task_class_counts=None, device="cpu", seed=1234,
-                 soft_labels=False):
+                 soft_labels=False, elevater=False, metric_names=None):
         self.num_classes = self._num_classes = num_classes
         self.classnames = [f"class {i}" for i in range(num_classes)]
         self.lab2cname = {i: n for i, n in enumerate(self.classnames)}
@@ -201,9 +201,24 @@ class SyntheticDataManager:
         self.num_source_domains = 1
         self._task_names, self._labelmap = [], {}
         self.task_class_counts = task_class_counts
+        self._task_class_idx, self._id2task = {}, {}
         if task_class_counts:
             self._task_names = [f"task{i}" for i in range(len(task_class_counts))]
             self._labelmap = {n: list(range(c)) for n, c in zip(self._task_names, task_class_counts)}
+            self._id2task = dict(enumerate(self._task_names))                       # trainers/mvlpt.py:780-790
+            lo = 0
+            for n, c in zip(self._task_names, task_class_counts):
+                self._task_class_idx[n] = (lo, lo + c)
+                lo += c
+        if elevater:                                                                # trainers/mvlpt.py:746-747, 782-783
+            from .metrics import get_metric
+            if task_class_counts:
+                names = list(metric_names or ["accuracy"] * len(task_class_counts))
+                self._metric_name = dict(zip(self._task_names, names))
+                self._metric = {t: get_metric(n) for t, n in self._metric_name.items()}
+            else:
+                self._metric_name = metric_names or "accuracy"
+                self._metric = get_metric(self._metric_name)
         B, R = cfg.DATALOADER.TRAIN_X.BATCH_SIZE, cfg.INPUT.SIZE[0]
         g = torch.Generator().manual_seed(seed)
         batches = []
@@ -216,9 +231,13 @@ class SyntheticDataManager:
                 lab = starts[dom] + (torch.rand(B, generator=g) * torch.tensor(task_class_counts)[dom]).long()
             else:
                 lab = torch.randint(0, num_classes, (B,), generator=g)
-            if soft_labels:
+            # ELEVATER targets: one-hot rows for multitask / multi-label metrics, plain ids for single-task accuracy
+            if soft_labels or (elevater and (task_class_counts or self._metric_name != "accuracy")):
                 lab = torch.nn.functional.one_hot(lab, num_classes).float()
-            batches.append({"img": img.to(device), "label": lab.to(device), "domain": dom})
+            if elevater:      # ELEVATER loaders yield (img, target, index string, task id)  (trainers/mvlpt.py:954-957)
+                batches.append((img.to(device), lab.to(device), [str(i) for i in range(B)], dom))
+            else:
+                batches.append({"img": img.to(device), "label": lab.to(device), "domain": dom})
         self.train_loader_x = batches
         self.train_loader_u = self.val_loader = None
         self.test_loader = batches[:1]
@@ -305,41 +324,78 @@ class MVLPT(TrainerX):
 
     @torch.no_grad()
     def test(self, split=None):
-        """Generic testing pipeline (trainers/mvlpt.py:989-1088, CoOp-data branch): top-1 accuracy overall and, for
-        multitask runs, per task on the task's own class range (:1035-1039).  Returns the headline accuracy (%)."""
+        """Generic testing pipeline (trainers/mvlpt.py:989-1088).  CoOp data (`cfg.DATASET.COOP`): top-1 accuracy in
+        percent, overall and — multitask — per task on the task's own class range (:1035-1039).  ELEVATER data: the
+        dataset's own metric (accuracy / mean-per-class / 11point_mAP / roc_auc, `dm._metric[_name]`) on the collected
+        logits, per task on the task's column slice (:1048-1060) or overall (:1076-1080).  Multitask runs return the
+        average over tasks or the task named by DATASET.MULTITASK_EVALKEY (:1068-1075).  Logits stay on the device
+        until the loader is exhausted (the reference copies every batch to the host, :1027-1028)."""
         self.set_model_mode("eval")
         split = split or self.cfg.TEST.SPLIT
         loader = self.val_loader if (split == "val" and self.val_loader is not None) else self.test_loader
+        coop = self.cfg.DATASET.COOP
         correct = torch.zeros((), device=self.device)
         total = 0
         per_task = {}
+        y_pred, y_true, y_task = [], [], []
         for batch in loader:
             input, label, tasks_ = self.parse_batch_test(batch)
             output = self.model_inference(input, task=tasks_)
+            if not coop:
+                y_pred.append(output.float())
+                y_true.append(label)
+                if tasks_ is not None:
+                    y_task.append(torch.as_tensor(tasks_).cpu())
+                continue
             if label.dim() > 1:
                 label = label.argmax(dim=1)
             correct += (output.argmax(dim=1) == label).sum()
             total += label.shape[0]
-            if tasks_ is not None and getattr(self.dm, "task_class_counts", None):
-                counts = self.dm.task_class_counts
-                starts = [0]
-                for c in counts[:-1]:
-                    starts.append(starts[-1] + c)
+            if tasks_ is not None and self._task_ranges() is not None:
+                ranges = self._task_ranges()
                 for t_id in set(tasks_.tolist()):
                     sel = (tasks_ == t_id).to(output.device)
-                    lo, hi = starts[t_id], starts[t_id] + counts[t_id]
+                    lo, hi = ranges[t_id]
                     hit = (output[sel][:, lo:hi].argmax(dim=1) + lo == label[sel]).sum()
                     acc = per_task.setdefault(t_id, [torch.zeros((), device=self.device), 0])
                     acc[0] += hit
                     acc[1] += int(sel.sum())
-        results = {"accuracy": 100.0 * float(correct) / max(total, 1)}
-        if per_task:
-            accs = {self.dm._task_names[t]: 100.0 * float(c) / max(n, 1) for t, (c, n) in per_task.items()}
+        results_overall = {}
+        if coop:
+            results = {"accuracy": 100.0 * float(correct) / max(total, 1)}
+            results_overall = {self.dm._task_names[t]: 100.0 * float(c) / max(n, 1) for t, (c, n) in per_task.items()}
+        else:
+            import numpy as np
+            pred = torch.cat(y_pred).cpu().numpy()
+            true = torch.cat(y_true).cpu().numpy()
+            if y_task:
+                task_ids = torch.cat(y_task).numpy()
+                for t_id in sorted(set(task_ids.tolist())):
+                    task = self.dm._id2task[t_id]
+                    lo, hi = self.dm._task_class_idx[task]
+                    yt, yp = true[task_ids == t_id][:, lo:hi], pred[task_ids == t_id][:, lo:hi]
+                    if self.dm._metric_name[task] == "accuracy":
+                        yt = np.argmax(yt, axis=-1)                                      # :1057-1058
+                    results_overall[task] = self.dm._metric[task](yt, yp)
+            else:
+                results = {self.dm._metric_name: self.dm._metric(true, pred)}            # :1076-1080
+        if self.multi_task and results_overall:
             key = self.cfg.DATASET.MULTITASK_EVALKEY
-            results = {"average": sum(accs.values()) / len(accs)} if key == "average" else {key: accs[key]}
-            self.last_task_results = accs
+            if key == "average":
+                results = {"average": sum(results_overall.values()) / len(results_overall)}
+            else:
+                assert key in results_overall
+                results = {key: results_overall[key]}
+        self.last_task_results = results_overall
         self.last_results = results
         return list(results.values())[0]
+
+    def _task_ranges(self):
+        """[(class_start, class_end)] per task id (trainers/mvlpt.py:785-790), or None for single-task data."""
+        idx = getattr(self.dm, "_task_class_idx", None)
+        if not idx:
+            return None
+        return [idx[name] for name in self.dm._task_names]
 
     def load_model(self, directory, epoch=None):
         if not directory:

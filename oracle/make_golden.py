@@ -212,9 +212,51 @@ def make_tokens(mv):
     print("[golden] tokens: name_lens", out["name_lens"].tolist())
 
 
+def make_metrics():
+    """ELEVATER metrics of the reference (trainers/vision_benchmark/datasets/metrics.py:1254-1294; needs sklearn) on
+    seeded score matrices: continuous scores, heavily tied scores, a class that never occurs, multi-label targets."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "ref_elevater_metrics", os.path.join(ref_shim.REFERENCE_ROOT, "trainers", "vision_benchmark", "datasets", "metrics.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.default_rng(11)
+    out = {}
+    cases = []
+    for i, (N, C, tied, skip, multilabel) in enumerate([(64, 7, False, False, False), (200, 10, True, False, False),
+                                                        (90, 12, False, True, False), (150, 5, False, False, True),
+                                                        (33, 2, True, False, False), (120, 20, True, True, True)]):
+        score = rng.normal(size=(N, C))
+        if tied:
+            score = np.round(score * 2) / 2
+        classes = np.arange(C) if not skip else np.delete(np.arange(C), [1, C - 1])
+        y = rng.choice(classes, size=N)
+        onehot = np.eye(C, dtype=np.int64)[y]
+        if multilabel:
+            extra = (rng.random(size=(N, C)) < 0.15).astype(np.int64)
+            if skip:
+                extra[:, [1, C - 1]] = 0
+            onehot = np.maximum(onehot, extra)
+        score = score + 1.5 * onehot * rng.random(size=(N, 1))          # informative scores
+        out[f"c{i}_score"], out[f"c{i}_y"], out[f"c{i}_onehot"] = score, y.astype(np.int64), onehot
+        out[f"c{i}_accuracy"] = np.float64(m.accuracy(y, score))                           # trainers/mvlpt.py:1062-1064
+        out[f"c{i}_mean_per_class"] = np.float64(m.balanced_accuracy_score(onehot, score))
+        out[f"c{i}_map11"] = np.float64(m.map_11_points(onehot, score))
+        if not skip:                                                    # sklearn raises on a single-valued column
+            out[f"c{i}_roc_auc"] = np.float64(m.roc_auc(onehot, score))
+        cases.append(i)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
+    print("[golden] metrics:", {k: float(v) for k, v in out.items() if k.endswith(("accuracy", "class", "map11", "auc"))})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = set(sys.argv[1:]) or {"tiny", "full", "tokens"}
+    which = set(sys.argv[1:]) or {"tiny", "full", "tokens", "metrics"}
+    if which == {"metrics"}:
+        return make_metrics()
+    if "metrics" in which:
+        make_metrics()
     torch.set_num_threads(8)
     mv, cm = ref_shim.load_reference()
     if "tokens" in which:

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def make_trainer(tmp_path, method="coop", classes=6, tasks=None, steps=4, B=8):
+def make_trainer(tmp_path, method="coop", classes=6, tasks=None, steps=4, B=8, elevater=False, metric_names=None):
     from mvlpt_amd.config import get_cfg_default
     from mvlpt_amd.trainer import MVLPT, SyntheticDataManager
     from mvlpt_amd.weights import ARCHS, make_state_dict
@@ -29,7 +29,9 @@ def make_trainer(tmp_path, method="coop", classes=6, tasks=None, steps=4, B=8):
     if tasks:
         cfg.DATASET.MULTITASK = True
         cfg.DATASET.MULTITASK_LABEL_PERTASK = True
-    dm = SyntheticDataManager(cfg, classes, steps, task_class_counts=tasks, device="cuda", seed=3)
+    cfg.DATASET.COOP = not elevater
+    dm = SyntheticDataManager(cfg, classes, steps, task_class_counts=tasks, device="cuda", seed=3, elevater=elevater,
+                              metric_names=metric_names)
     return MVLPT(cfg, dm=dm, clip_state_dict=make_state_dict(ARCHS["tiny"], seed=9))
 
 
@@ -73,6 +75,38 @@ def test_eval_accuracy_and_text_cache(tmp_path):
     tr.forward_backward(tr.train_loader_x[0])                    # SGD step bumps the parameter versions
     tr.test()
     assert model._eval_text_cache[0] != ver0
+
+
+def test_elevater_eval_branch_uses_the_task_metrics(tmp_path):
+    """ELEVATER data (tuple batches, one-hot targets): per-task metric on the task's column slice, then the average
+    (trainers/mvlpt.py:1048-1075), recomputed here from the model's own logits."""
+    import numpy as np
+    from mvlpt_amd import metrics as M
+    names = ["accuracy", "mean-per-class", "11point_mAP"]
+    tr = make_trainer(tmp_path, "coop", classes=9, tasks=[3, 2, 4], B=32, elevater=True, metric_names=names)
+    tr.test_loader = tr.train_loader_x                         # 4 batches
+    got = tr.test()
+    assert set(tr.last_task_results) == {"task0", "task1", "task2"}
+    preds, trues, tasks = [], [], []
+    with torch.no_grad():
+        for img, lab, _idx, task in tr.test_loader:
+            preds.append(tr.model(img, task=task).float().cpu().numpy())
+            trues.append(lab.cpu().numpy())
+            tasks.append(task.numpy())
+    pred, true, task = np.concatenate(preds), np.concatenate(trues), np.concatenate(tasks)
+    want = {}
+    for t, (lo, hi) in enumerate([(0, 3), (3, 5), (5, 9)]):
+        yt, yp = true[task == t][:, lo:hi], pred[task == t][:, lo:hi]
+        if names[t] == "accuracy":
+            yt = yt.argmax(-1)
+        want[f"task{t}"] = M.get_metric(names[t])(yt, yp)
+    for k in want:
+        assert abs(want[k] - tr.last_task_results[k]) < 1e-12, k
+    assert abs(got - sum(want.values()) / 3) < 1e-12
+    # single-task ELEVATER data: the dataset's own metric over all classes (:1076-1080)
+    tr1 = make_trainer(tmp_path, "vpt", classes=5, B=16, elevater=True, metric_names="roc_auc")
+    auc = tr1.test()
+    assert 0.0 <= auc <= 1.0 and list(tr1.last_results) == ["roc_auc"]
 
 
 def test_step_pipelining_is_transparent(tmp_path):
