@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       qf[i][1] = *(const v8*)(qp + 32);
     }
   }
-  stage_rows_dma<T>(sK, base + d, ld, L, LP, wave, lane);
-  stage_rows_dma<T>(sV, base + 2 * d, ld, L, LP, wave, lane);
+  stage_rows_dma<T>(sK, base + d, ld, L, LP, wave, lane, a.flags & 1);
+  stage_rows_dma<T>(sV, base + 2 * d, ld, L, LP, wave, lane, a.flags & 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         v4 w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(o[dt][e] * inv);
-        *(v4*)(op + dt * 16) = w;
+        if (a.flags & 2) __builtin_nontemporal_store(w, (v4*)(op + dt * 16));
+        else *(v4*)(op + dt * 16) = w;
       }
       // natural-log LSE of the scaled scores (the backward recomputes P = exp(s/8 - lse))
       if (a.lse && fg == 0) a.lse[((size_t)n * H + h) * L + qrow] = (mrun + log2f(sum)) * 0.6931471805599453f;
@@ -187,8 +188,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < MAXQ; ++i) pre[i] = load_ops(wave + 4 * i);
   }
-  stage_rows_dma<T>(sK, base + d, ld, L, LP, wave, lane);
-  stage_rows_dma<T>(sV, base + 2 * d, ld, L, LP, wave, lane);
+  stage_rows_dma<T>(sK, base + d, ld, L, LP, wave, lane, a.flags & 1);
+  stage_rows_dma<T>(sV, base + 2 * d, ld, L, LP, wave, lane, a.flags & 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -303,8 +304,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
     sLse[i] = i < L ? a.lse[((size_t)n * H + h) * L + i] : 0.f;
     sDel[i] = i < L ? a.delta[((size_t)n * H + h) * L + i] : 0.f;
   }
-  stage_rows_dma<T>(sQ, base, ld, L, LP, wave, lane);
-  stage_rows_dma<T>(sdO, dob, (size_t)d, L, LP, wave, lane);
+  stage_rows_dma<T>(sQ, base, ld, L, LP, wave, lane, a.flags & 1);
+  stage_rows_dma<T>(sdO, dob, (size_t)d, L, LP, wave, lane, a.flags & 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -436,7 +437,10 @@ static bool use_stream(int L, bool bwd) {
   return L > 256;
 }
 
-hipError_t launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s) {
+hipError_t launch_attn_fwd(int dtype, const AttnArgs& a_, hipStream_t s) {
+  static const int flags = [] { const char* e = getenv("MVLPT_ATTN_FLAGS"); return e ? atoi(e) : 3; }();
+  AttnArgs a = a_;
+  a.flags = flags;
   if (a.L <= 0 || a.L > attn_max_len() || a.N <= 0) return hipErrorInvalidValue;
   if (use_stream(a.L, false)) return launch_attn_fwd_stream(dtype, a, s);
   const int nkt = nkt_for(a.L);
@@ -444,7 +448,10 @@ hipError_t launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s) {
   if (dtype == DT_BF16) return a.causal ? fwd_n<bf16, true>(nkt, a, s) : fwd_n<bf16, false>(nkt, a, s);
   return hipErrorInvalidValue;
 }
-hipError_t launch_attn_bwd(int dtype, const AttnBwdArgs& a, hipStream_t s) {
+hipError_t launch_attn_bwd(int dtype, const AttnBwdArgs& a_, hipStream_t s) {
+  static const int flags = [] { const char* e = getenv("MVLPT_ATTNB_FLAGS"); return e ? atoi(e) : 0; }();
+  AttnBwdArgs a = a_;
+  a.flags = flags;
   if (a.L <= 0 || a.L > attn_max_len() || a.N <= 0) return hipErrorInvalidValue;
   if (use_stream(a.L, true)) return launch_attn_bwd_stream(dtype, a, s);
   const int nkt = nkt_for(a.L);

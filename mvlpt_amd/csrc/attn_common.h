@@ -12,12 +12,13 @@ namespace mvlpt {
 // per-lane SOURCE address.  Rows >= L re-read row L-1 (finite values; they only ever meet P = 0 / masked scores).
 // The caller waits with s_waitcnt vmcnt(0) + barrier before the first ds_read.
 template <typename T>
-__device__ __forceinline__ void stage_rows_dma(char* dst, const T* src, size_t ld, int L, int LP, int wave, int lane) {
+__device__ __forceinline__ void stage_rows_dma(char* dst, const T* src, size_t ld, int L, int LP, int wave, int lane, bool nt = false) {
   const int srow = lane >> 3, chunk = (lane & 7) ^ srow;
   for (int sl = wave; sl < LP / 8; sl += 4) {
     int row = sl * 8 + srow;
     row = row < L ? row : L - 1;
-    glds16(src + (size_t)row * ld + chunk * 8, dst + sl * 1024);
+    if (nt) glds16_nt(src + (size_t)row * ld + chunk * 8, dst + sl * 1024);
+    else glds16(src + (size_t)row * ld + chunk * 8, dst + sl * 1024);
   }
 }
 // A-operand fragment of a row-major swizzled image: rows tile*16 + (lane&15), k-step ks (32 wide)

@@ -64,6 +64,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// same with the non-temporal (streaming) cache policy: for operands that exactly one workgroup reads once
+__device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+
 enum DType { DT_F32 = 0, DT_F16 = 1, DT_BF16 = 2 };
 
 }  // namespace mvlpt

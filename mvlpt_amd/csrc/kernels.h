@@ -22,6 +22,7 @@ struct GemmArgs {
   const float* resid;  // [M,N] fp32   (EPI_RESID32)
   void* out;           // [M,N]
   void* out2;          // [M,N] 16-bit, optional (EPI_GELU)
+  int cached_out = 0;  // EPI_RESID32: 1 = ordinary (cache-allocating) stores of the fp32 output instead of non-temporal
 };
 // ev_start/ev_stop (optional): recorded by the dispatch itself (hipExtLaunchKernelGGL): kernel-exact timing with no
 // extra marker packets on the stream.
@@ -60,12 +61,14 @@ struct AttnArgs {
   const void* qkv; void* out /*[N*L,d]*/; float* lse /*[N*H*L] or null*/;
   int N, L, H; int causal;
   int q_rows = 0;   // > 0: only queries 0..q_rows-1 of every sequence are computed (last layer: only CLS is consumed)
+  int flags = 0;    // experiment bits: 1 = non-temporal K/V staging, 2 = non-temporal output stores
 };
 hipError_t launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s);
 struct AttnBwdArgs {
   const void* qkv; const void* out; const void* dout; const float* lse;
   float* delta /*[N*H*L] scratch*/; void* dqkv /*[N*L,3d]*/;
   int N, L, H; int causal;
+  int flags = 0;    // 1 = non-temporal staging of the operands
 };
 hipError_t launch_attn_bwd(int dtype, const AttnBwdArgs& a, hipStream_t s);
 int attn_max_len();
