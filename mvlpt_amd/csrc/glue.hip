@@ -164,64 +164,86 @@ hipError_t launch_patchify(int dtype, const void* image, int image_dtype, void* 
 
 // One wave per token row of x [B, 1+n+G2, d].  row 0: ln_pre(cls + pos[0]); rows 1..n: visual prompts, raw
 // (no positional embedding, no ln_pre: trainers/mvlpt.py:57-62, 416-437); others: ln_pre(patch + pos[1+i]).
+// Grid-stride: resident waves walk the rows, the next row's patch-embedding loads are in flight while the current
+// row is normalised; gamma/beta stay in registers; streamed fp32 operands use non-temporal loads/stores.
+template <int NV>
 __global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
                                                               const float* __restrict__ pos, const float* __restrict__ g,
                                                               const float* __restrict__ bt, const float* __restrict__ vpt,
                                                               int n_vpt, float* __restrict__ x, int B, int G2, int d) {
   const int lane = threadIdx.x & 63;
   const int L = 1 + n_vpt + G2;
-  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (size_t)B * L) return;
-  const int b = (int)(row / L), i = (int)(row % L);
-  float* xo = x + row * d;
-  if (i >= 1 && i <= n_vpt) {
-    const float* src = vpt + (size_t)(i - 1) * d;
-    for (int c = lane * 4; c < d; c += 256) *(f32x4*)(xo + c) = *(const f32x4*)(src + c);
-    return;
-  }
-  const int pi = i == 0 ? 0 : i - n_vpt;                    // positional row
-  const float* src = i == 0 ? cls : pe + ((size_t)b * G2 + (pi - 1)) * d;
-  const float* pp = pos + (size_t)pi * d;
-  constexpr int MAXV = 8;                                   // d <= 2048, row held in registers
-  f32x4 v[MAXV];
-  float s = 0.f;
+  const size_t rows = (size_t)B * L, nw = (size_t)gridDim.x * 4;
+  size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  bool ok[NV]; f32x4 gg[NV], bb[NV], cur[NV], nxt[NV];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
+  for (int k = 0; k < NV; ++k) {
     const int c = (k * 64 + lane) * 4;
-    v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c < d) {
-      v[k] = *(const f32x4*)(src + c) + *(const f32x4*)(pp + c);
-      s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
-    }
+    ok[k] = c < d;
+    gg[k] = ok[k] ? *(const f32x4*)(g + c) : zero;
+    bb[k] = ok[k] ? *(const f32x4*)(bt + c) : zero;
   }
-  const float mean = wave_sum(s) / (float)d;
-  float q = 0.f;
+  // raw source row (before + pos): prompts rows come from vpt, row 0 from cls, the rest from the patch embedding
+  auto load_row = [&](size_t r, f32x4* v) {
+    const int b = (int)(r / L), i = (int)(r % L);
+    const bool prompt = i >= 1 && i <= n_vpt;
+    const float* src = prompt ? vpt + (size_t)(i - 1) * d : (i == 0 ? cls : pe + ((size_t)b * G2 + (i - n_vpt - 1)) * d);
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
-    if ((k * 64 + lane) * 4 < d) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { const float t = v[k][e] - mean; q += t * t; }
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * 64 + lane) * 4;
+      v[k] = !ok[k] ? zero : (prompt || i == 0) ? *(const f32x4*)(src + c) : __builtin_nontemporal_load((const f32x4*)(src + c));
     }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+  };
+  if (row < rows) load_row(row, cur);
+  for (; row < rows; row += nw) {
+    if (row + nw < rows) load_row(row + nw, nxt);
+    const int i = (int)(row % L);
+    float* xo = x + row * d;
+    if (i >= 1 && i <= n_vpt) {
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
-    const int c = (k * 64 + lane) * 4;
-    if (c < d) {
-      const f32x4 gg = *(const f32x4*)(g + c), bb = *(const f32x4*)(bt + c);
-      f32x4 o;
+      for (int k = 0; k < NV; ++k) if (ok[k]) __builtin_nontemporal_store(cur[k], (f32x4*)(xo + (k * 64 + lane) * 4));
+    } else {
+      const float* pp = pos + (size_t)(i == 0 ? 0 : i - n_vpt) * d;
+      float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mean) * rstd * gg[e] + bb[e];
-      *(f32x4*)(xo + c) = o;
+      for (int k = 0; k < NV; ++k) if (ok[k]) {
+        cur[k] += *(const f32x4*)(pp + (k * 64 + lane) * 4);
+        s += cur[k][0] + cur[k][1] + cur[k][2] + cur[k][3];
+      }
+      const float mean = wave_sum(s) / (float)d;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) if (ok[k]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = cur[k][e] - mean; q += t * t; }
+      }
+      const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) if (ok[k]) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (cur[k][e] - mean) * rstd * gg[k][e] + bb[k][e];
+        __builtin_nontemporal_store(o, (f32x4*)(xo + (k * 64 + lane) * 4));
+      }
     }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) cur[k] = nxt[k];
   }
 }
 hipError_t launch_assemble_tokens(const float* patch_emb, const float* cls, const float* pos, const float* g, const float* b,
                                   const float* vpt, int n_vpt, float* x, int B, int G2, int d, hipStream_t s) {
   if (d % 4 || d > 2048) return hipErrorInvalidValue;
   const size_t rows = (size_t)B * (1 + n_vpt + G2);
-  hipLaunchKernelGGL(assemble_tokens_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, patch_emb, cls, pos, g, b, vpt,
-                     n_vpt, x, B, G2, d);
+  const size_t want = (rows + 3) / 4;
+  const dim3 grid((unsigned)(want < 2048 ? want : 2048)), block(256);
+  const int nv = (d + 255) / 256;
+#define MVLPT_ASM_TOK(NV) hipLaunchKernelGGL(assemble_tokens_kernel<NV>, grid, block, 0, s, patch_emb, cls, pos, g, b, vpt, n_vpt, x, B, G2, d)
+  if (nv <= 2) MVLPT_ASM_TOK(2);
+  else if (nv == 3) MVLPT_ASM_TOK(3);
+  else if (nv == 4) MVLPT_ASM_TOK(4);
+  else MVLPT_ASM_TOK(8);
+#undef MVLPT_ASM_TOK
   return hipGetLastError();
 }
 
@@ -243,25 +265,44 @@ hipError_t launch_overwrite_rows(const float* rows, int n, float* x, int B, int 
 
 // out[j,:] = inv_scale * sum_b dx32[b, row0+j, :]   (prompt rows are `expand`ed over the batch => sum over B);
 // optionally zero those rows afterwards (deep prompts overwrite the rows: upstream gradient is 0).
+// 16 waves per block: wave w sums images w, w+16, ... (all loads of a wave independent -> one memory latency, not B),
+// lane = one float4 column; the 16 partials are added in a fixed order through LDS (deterministic, no atomics).
 template <typename T>
-__global__ void reduce_prompt_rows_kernel(float* __restrict__ dx32, T* __restrict__ dx16, int B, int L, int d, int row0,
-                                          int n, float* __restrict__ out, const float* scale_dev, int zero_after) {
+__global__ __launch_bounds__(1024) void reduce_prompt_rows_kernel(float* __restrict__ dx32, T* __restrict__ dx16, int B, int L, int d,
+                                                                  int row0, int n, float* __restrict__ out, const float* scale_dev,
+                                                                  int zero_after) {
+  __shared__ f32x4 part[16][64];
   const int j = blockIdx.y;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d) return;
-  const float inv = scale_dev ? scale_dev[1] : 1.0f;
-  float acc = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const size_t o = ((size_t)b * L + row0 + j) * d + c;
-    acc += dx32[o];
-    if (zero_after) { dx32[o] = 0.f; if (dx16) dx16[o] = (T)0.f; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const bool ok = c < d;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+#pragma unroll 8
+    for (int b = wave; b < B; b += 16) {
+      const size_t o = ((size_t)b * L + row0 + j) * d + c;
+      acc += *(const f32x4*)(dx32 + o);
+      if (zero_after) {
+        *(f32x4*)(dx32 + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (dx16) { typename Vec<T>::v4 z; for (int e = 0; e < 4; ++e) z[e] = (T)0.f; *(typename Vec<T>::v4*)(dx16 + o) = z; }
+      }
+    }
   }
-  out[(size_t)j * d + c] = acc * inv;
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && ok) {
+    f32x4 t = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t += part[w][lane];
+    const float inv = scale_dev ? scale_dev[1] : 1.0f;
+    *(f32x4*)(out + (size_t)j * d + c) = t * inv;
+  }
 }
 hipError_t launch_reduce_prompt_rows(int dtype, float* dx32, void* dx16, int B, int L, int d, int row0, int n, float* out,
                                      const float* scale_dev, int zero_after, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  dim3 grid((d + 255) / 256, n), block(256);
+  if (d % 4) return hipErrorInvalidValue;
+  dim3 grid((d + 255) / 256, n), block(1024);
   if (dtype == DT_F16) hipLaunchKernelGGL(reduce_prompt_rows_kernel<f16>, grid, block, 0, s, dx32, (f16*)dx16, B, L, d, row0, n, out, scale_dev, zero_after);
   else if (dtype == DT_BF16) hipLaunchKernelGGL(reduce_prompt_rows_kernel<bf16>, grid, block, 0, s, dx32, (bf16*)dx16, B, L, d, row0, n, out, scale_dev, zero_after);
   else return hipErrorInvalidValue;
