@@ -193,7 +193,7 @@ void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool s
     st.dx16 = bp.take_bytes(T * d * 2); st.dh32 = bp.take<float>(T * d); st.dO16 = bp.take_bytes(T * d * 2);
     st.du16 = bp.take_bytes(T * 4 * d * 2); st.dqkv16 = bp.take_bytes(T * 3 * d * 2);
     st.delta = bp.take<float>((size_t)N * H * L);
-    st.scale_dev = bp.take<float>(2);
+    st.scale_dev = bp.take<float>(4);   // {scale, 1/scale, amax scratch, pad}
   }
   st.valid = true;
 }

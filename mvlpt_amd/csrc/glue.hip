@@ -362,26 +362,48 @@ hipError_t launch_eot_rows(const int32_t* eot, int32_t* rows, int C, int L, hipS
 
 // generic ctx: dctx[j,:] = inv * sum_c dx[c, pos(c,j), :]  (ctx is expanded over classes: trainers/mvlpt.py:455-456)
 // class-specific (CSC): dctx[c,j,:] = inv * dx[c, pos(c,j), :]
-__global__ void gather_ctx_grad_kernel(const float* __restrict__ dx, const int32_t* __restrict__ ctx_pos, int C, int L, int d,
-                                       int n_ctx, int per_class, float* __restrict__ dctx, const float* scale_dev) {
-  const int j = blockIdx.y;
+__global__ void gather_ctx_grad_csc_kernel(const float* __restrict__ dx, const int32_t* __restrict__ ctx_pos, int L, int d,
+                                           int n_ctx, float* __restrict__ dctx, const float* scale_dev) {
+  const int j = blockIdx.y, cls = blockIdx.z;
   const int c0 = blockIdx.x * blockDim.x + threadIdx.x;
   if (c0 >= d) return;
   const float inv = scale_dev ? scale_dev[1] : 1.0f;
-  if (per_class) {
-    const int cls = blockIdx.z;
-    dctx[((size_t)cls * n_ctx + j) * d + c0] = inv * dx[((size_t)cls * L + ctx_pos[cls * n_ctx + j]) * d + c0];
-  } else {
-    float acc = 0.f;
-    for (int cls = 0; cls < C; ++cls) acc += dx[((size_t)cls * L + ctx_pos[cls * n_ctx + j]) * d + c0];
-    dctx[(size_t)j * d + c0] = acc * inv;
+  dctx[((size_t)cls * n_ctx + j) * d + c0] = inv * dx[((size_t)cls * L + ctx_pos[cls * n_ctx + j]) * d + c0];
+}
+// generic context: 16 waves per block, wave w sums classes w, w+16, ... (independent loads), lane = float4 column;
+// partials are added in a fixed order through LDS (deterministic)
+__global__ __launch_bounds__(1024) void gather_ctx_grad_kernel(const float* __restrict__ dx, const int32_t* __restrict__ ctx_pos,
+                                                               int C, int L, int d, int n_ctx, float* __restrict__ dctx,
+                                                               const float* scale_dev) {
+  __shared__ f32x4 part[16][64];
+  const int j = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const bool ok = c < d;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+#pragma unroll 8
+    for (int cls = wave; cls < C; cls += 16)
+      acc += *(const f32x4*)(dx + ((size_t)cls * L + ctx_pos[cls * n_ctx + j]) * d + c);
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && ok) {
+    f32x4 t = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t += part[w][lane];
+    const float inv = scale_dev ? scale_dev[1] : 1.0f;
+    *(f32x4*)(dctx + (size_t)j * d + c) = t * inv;
   }
 }
 hipError_t launch_gather_ctx_grad(const float* dx, const int32_t* ctx_pos, int C, int L, int d, int n_ctx, int per_class,
                                   float* dctx, const float* scale_dev, hipStream_t s) {
   if (n_ctx <= 0) return hipSuccess;
-  dim3 grid((d + 255) / 256, n_ctx, per_class ? C : 1), block(256);
-  hipLaunchKernelGGL(gather_ctx_grad_kernel, grid, block, 0, s, dx, ctx_pos, C, L, d, n_ctx, per_class, dctx, scale_dev);
+  if (d % 4) return hipErrorInvalidValue;
+  if (per_class)
+    hipLaunchKernelGGL(gather_ctx_grad_csc_kernel, dim3((d + 255) / 256, n_ctx, C), dim3(256), 0, s, dx, ctx_pos, L, d, n_ctx, dctx, scale_dev);
+  else
+    hipLaunchKernelGGL(gather_ctx_grad_kernel, dim3((d + 255) / 256, n_ctx), dim3(1024), 0, s, dx, ctx_pos, C, L, d, n_ctx, dctx, scale_dev);
   return hipGetLastError();
 }
 
@@ -389,28 +411,32 @@ hipError_t launch_gather_ctx_grad(const float* dx, const int32_t* ctx_pos, int C
 // The backward is linear in the incoming gradient, so it is run on  2^k * dfeat  to keep 16-bit activation
 // gradients in range (the reference's fp16 mode has no GradScaler, trainers/mvlpt.py:873,927-932, and simply
 // underflows); prompt gradients are multiplied by 2^-k when they are reduced.  Single block, deterministic.
-__global__ __launch_bounds__(1024) void grad_scale_kernel(const float* __restrict__ v, size_t n, float target, float* scale_dev) {
-  __shared__ float red[16];
+// stage 1: amax over many blocks (max is order-independent: atomicMax on the bit pattern of |v| is deterministic);
+// stage 2: one thread turns it into the power-of-two scale.  scale_dev = {scale, 1/scale, amax bits (scratch)}.
+__global__ __launch_bounds__(256) void grad_amax_kernel(const float* __restrict__ v, size_t n, float* scale_dev) {
   float m = 0.f;
-  for (size_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(v[i]));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(v[i]));
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
-    float sc = 1.0f;
-    if (m > 0.f && isfinite(m)) {
-      int e; frexpf(m, &e);                      // m = f * 2^e, f in [0.5, 1)
-      int et; frexpf(target, &et);
-      int k = et - e; k = k > 60 ? 60 : (k < -60 ? -60 : k);
-      sc = ldexpf(1.0f, k);
-    }
-    scale_dev[0] = sc;
-    scale_dev[1] = 1.0f / sc;
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)(scale_dev + 2), __float_as_uint(m));   // m >= 0 (NaN/inf sort on top)
+}
+__global__ void grad_scale_finish_kernel(float target, float* scale_dev) {
+  const float m = __uint_as_float(*(const unsigned*)(scale_dev + 2));
+  float sc = 1.0f;
+  if (m > 0.f && isfinite(m)) {
+    int e; frexpf(m, &e);                      // m = f * 2^e, f in [0.5, 1)
+    int et; frexpf(target, &et);
+    int k = et - e; k = k > 60 ? 60 : (k < -60 ? -60 : k);
+    sc = ldexpf(1.0f, k);
   }
+  scale_dev[0] = sc;
+  scale_dev[1] = 1.0f / sc;
 }
 hipError_t launch_grad_scale(const float* v, size_t n, float target, float* scale_dev, hipStream_t s) {
-  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1024), 0, s, v, n, target, scale_dev);
+  hipError_t e = hipMemsetAsync(scale_dev + 2, 0, sizeof(float), s);
+  if (e != hipSuccess) return e;
+  const size_t want = (n + 1023) / 1024;
+  hipLaunchKernelGGL(grad_amax_kernel, dim3((unsigned)(want < 512 ? (want ? want : 1) : 512)), dim3(256), 0, s, v, n, scale_dev);
+  hipLaunchKernelGGL(grad_scale_finish_kernel, dim3(1), dim3(1), 0, s, target, scale_dev);
   return hipGetLastError();
 }
 
