@@ -106,6 +106,30 @@ int mvlpt_op_attention_bwd(int dtype, const void* qkv, const void* out, const vo
                            void* dqkv, int N, int L, int H, int causal, mvlpt_stream_t stream);
 int mvlpt_op_cast(int dtype, const float* in, void* out, int64_t n, mvlpt_stream_t stream);
 
+/* ---- input pipeline ("next" row f3 of the scope table) -------------------------------------------------------
+ * Replaces the per-image CPU transform the reference runs in DataLoader workers: Dassl `build_transform` with
+ * INPUT.TRANSFORMS = random_resized_crop / random_flip / normalize, INTERPOLATION bicubic, CLIP PIXEL_MEAN/STD
+ * (configs/trainers/MVLPT/vit_b16.yaml:8-13), and the ELEVATER eval transform Resize(BICUBIC) [+ CenterCrop] +
+ * ToTensor + Normalize (trainers/vision_benchmark/evaluation/feature.py:538-553).  Both are torchvision ops on PIL
+ * images: `img.crop(box).resize((rw, rh), BICUBIC)` [+ window] [+ horizontal flip], u8/255, (x - mean)/std.
+ * The random parameters (crop box, flip) are drawn by the caller (host RNG, as torchvision does).
+ * Results are bit-identical to Pillow (8-bit resample) and torch CPU (fp32 arithmetic). */
+typedef struct MvlptImageDesc {
+  int64_t offset;                 /* byte offset of pixel (0,0) in `src`; image = uint8 HWC, 3 channels, row stride 3*width */
+  int32_t height, width;
+  int32_t crop_top, crop_left, crop_height, crop_width;   /* PIL crop box, inside the image */
+  int32_t resize_height, resize_width;                    /* size the crop is resampled to */
+  int32_t out_top, out_left;                              /* window [out_top, out_top+out_h) x [out_left, out_left+out_w)
+                                                             of the resized image that is produced (CenterCrop); 0, 0 if none */
+  int32_t flip;                                           /* 1 = horizontal flip of the produced window */
+  int32_t reserved;
+} MvlptImageDesc;
+/* src: device, packed decoded images; descs: HOST array of B descriptors (uploaded on `stream`);
+ * out: device [B,3,out_h,out_w] of out_dtype (MVLPT_DT_*), may be NULL; out_u8: device [B,out_h,out_w,3] resized 8-bit
+ * image before ToTensor (may be NULL; parity tests).  mean/std: 3 host floats each. */
+int mvlpt_preprocess(void* handle, const uint8_t* src, int64_t src_bytes, const MvlptImageDesc* descs, int B, int out_h, int out_w,
+                     const float* mean, const float* std, void* out, int out_dtype, uint8_t* out_u8, mvlpt_stream_t stream);
+
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) --------------------- */
 typedef struct MvlptKernelStat {
   char name[32];

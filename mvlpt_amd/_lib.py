@@ -28,6 +28,12 @@ class MvlptKernelStat(C.Structure):
                 ("flops", C.c_double), ("bytes", C.c_double), ("busy_ms", C.c_double)]
 
 
+class MvlptImageDesc(C.Structure):
+    _fields_ = [("offset", C.c_int64)] + [(n, C.c_int32) for n in (
+        "height", "width", "crop_top", "crop_left", "crop_height", "crop_width", "resize_height", "resize_width",
+        "out_top", "out_left", "flip", "reserved")]
+
+
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 # name -> (restype, argtypes): every symbol include/mvlpt_hip.h declares
@@ -51,6 +57,7 @@ SIGNATURES = {
     "mvlpt_op_attention_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvlpt_op_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvlpt_op_cast": (_i, [_i, _vp, _vp, C.c_int64, _vp]),
+    "mvlpt_preprocess": (_i, [_vp, _vp, C.c_int64, C.POINTER(MvlptImageDesc), _i, _i, _i, C.POINTER(_f), C.POINTER(_f), _vp, _i, _vp, _vp]),
     "mvlpt_profile_begin": (_i, [_vp, _i]),
     "mvlpt_profile_pause": (_i, [_vp, _i]),
     "mvlpt_profile_end": (_i, [_vp, C.POINTER(MvlptKernelStat), _i]),

@@ -84,7 +84,7 @@ struct Engine {
   // text extras
   float* tpos = nullptr; LNp ln_final; float *tproj = nullptr, *tproj_t = nullptr;
   std::vector<void*> owned;               // every weight allocation (freed in destroy)
-  DevBuf vis_ws, txt_ws, head_ws, ce_ws, tmp;
+  DevBuf vis_ws, txt_ws, head_ws, ce_ws, tmp, pp_ws;
   TowerState vs, ts;
   // vision fwd extras (carved from vis_ws)
   int vB = 0, v_nvpt = 0, v_ndeep = 0; float* cls32 = nullptr; float* dcls32 = nullptr;
@@ -707,6 +707,44 @@ int mvlpt_op_attention_bwd(int dtype, const void* qkv, const void* out, const vo
 }
 int mvlpt_op_cast(int dtype, const float* in, void* out, int64_t n, mvlpt_stream_t stream) {
   OPCHK(launch_cast_f32_to16(dtype, in, out, (size_t)n, nullptr, (hipStream_t)stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ input pipeline
+int mvlpt_preprocess(void* h, const uint8_t* src, int64_t src_bytes, const MvlptImageDesc* descs, int B, int out_h, int out_w,
+                     const float* mean, const float* stdv, void* out, int out_dtype, uint8_t* out_u8, mvlpt_stream_t stream) {
+  static_assert(sizeof(MvlptImageDesc) == sizeof(PpDesc), "descriptor layouts must match");
+  Engine* E = (Engine*)h;
+  if (!E) return MVLPT_ERR_ARG;
+  if (!src || !descs || B <= 0 || out_h <= 0 || out_w <= 0 || !mean || !stdv || (!out && !out_u8))
+    return fail(E, MVLPT_ERR_ARG, "preprocess: null pointer or empty batch / output");
+  if (out && out_dtype != DT_F32 && out_dtype != DT_F16 && out_dtype != DT_BF16) return fail(E, MVLPT_ERR_ARG, "preprocess: bad out_dtype");
+  int max_crop_h = 0, ks_max = 1;
+  for (int b = 0; b < B; ++b) {
+    const MvlptImageDesc& d = descs[b];
+    const bool ok = d.height > 0 && d.width > 0 && d.offset >= 0 && d.offset + (int64_t)d.height * d.width * 3 <= src_bytes &&
+                    d.crop_top >= 0 && d.crop_left >= 0 && d.crop_height > 0 && d.crop_width > 0 &&
+                    d.crop_top + d.crop_height <= d.height && d.crop_left + d.crop_width <= d.width && d.resize_height > 0 &&
+                    d.resize_width > 0 && d.out_top >= 0 && d.out_left >= 0 && d.out_top + out_h <= d.resize_height &&
+                    d.out_left + out_w <= d.resize_width && (d.flip == 0 || d.flip == 1);
+    if (!ok) return fail(E, MVLPT_ERR_ARG, "preprocess: descriptor " + std::to_string(b) + " is inconsistent (box / window outside the image, or image outside src)");
+    max_crop_h = std::max(max_crop_h, (int)d.crop_height);
+    const double sh = std::max(1.0, (double)d.crop_height / d.resize_height), sw = std::max(1.0, (double)d.crop_width / d.resize_width);
+    ks_max = std::max(ks_max, std::max((int)std::ceil(2.0 * sh), (int)std::ceil(2.0 * sw)) * 2 + 1);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int n_max = std::max(out_h, out_w);
+  const size_t table_stride = (size_t)(2 + ks_max) * n_max;                          // int32 per (image, pass)
+  const size_t tmp_stride = align256((size_t)max_crop_h * out_w * 3);
+  const size_t desc_bytes = align256(sizeof(PpDesc) * (size_t)B), table_bytes = align256(table_stride * 4 * 2 * (size_t)B);
+  HIPCHK(E, E->pp_ws.reserve(desc_bytes + table_bytes + tmp_stride * (size_t)B));
+  char* base = (char*)E->pp_ws.p;
+  PpDesc* descs_dev = (PpDesc*)base;
+  int32_t* tables = (int32_t*)(base + desc_bytes);
+  uint8_t* tmp = (uint8_t*)(base + desc_bytes + table_bytes);
+  HIPCHK(E, hipMemcpyAsync(descs_dev, descs, sizeof(PpDesc) * (size_t)B, hipMemcpyHostToDevice, s));
+  HIPCHK(E, launch_preprocess(src, descs_dev, B, max_crop_h, ks_max, out_h, out_w, tables, table_stride, tmp, tmp_stride, mean, stdv,
+                              out, out_dtype, out_u8, s));
   return 0;
 }
 

@@ -76,6 +76,20 @@ int attn_max_len();
 hipError_t launch_attn_fwd_stream(int dtype, const AttnArgs& a, hipStream_t s);
 hipError_t launch_attn_bwd_stream(int dtype, const AttnBwdArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- input pipeline (preprocess.hip)
+// same layout as MvlptImageDesc (include/mvlpt_hip.h)
+struct PpDesc {
+  int64_t offset;                            // byte offset of pixel (0,0) of this image in the packed uint8 HWC source
+  int32_t height, width;
+  int32_t crop_top, crop_left, crop_h, crop_w;
+  int32_t resize_h, resize_w;                // size the crop box is resampled to
+  int32_t out_top, out_left;                 // window of the resized image that is produced (CenterCrop); 0,0 for training
+  int32_t flip, reserved;
+};
+hipError_t launch_preprocess(const uint8_t* src, const PpDesc* descs_dev, int B, int max_crop_h, int ks_max, int out_h, int out_w,
+                             int32_t* tables, size_t table_stride, uint8_t* tmp, size_t tmp_stride, const float* mean,
+                             const float* stdv, void* out, int out_dtype, uint8_t* out_u8, hipStream_t s);
+
 // ---------------------------------------------------------------- glue
 hipError_t launch_cast_f32_to16(int dtype, const float* in, void* out, size_t n, const float* scale_dev, hipStream_t s);
 hipError_t launch_cast_any_to_f32(int in_dtype, const void* in, float* out, size_t n, hipStream_t s);

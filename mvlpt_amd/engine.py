@@ -194,6 +194,23 @@ class Engine:
                                            _stream()), self.h, "cross_entropy")
         return loss, dl, nc
 
+    # ------------------------------------------------------------------ input pipeline
+    def preprocess(self, src: torch.Tensor, descs, out_size, mean, std, out_dtype=torch.float32, want_u8: bool = False):
+        """src: uint8 device tensor holding the packed decoded HWC images; descs: `_lib.MvlptImageDesc` ctypes array.
+        Returns [B,3,h,w] normalised images (and the resized 8-bit images [B,h,w,3] when `want_u8`)."""
+        if not src.is_cuda or src.dtype != torch.uint8:
+            raise RuntimeError("src must be a uint8 CUDA/HIP tensor: mvlpt_amd has no CPU path")
+        src = src.contiguous()
+        B = len(descs)
+        oh, ow = (out_size, out_size) if isinstance(out_size, int) else tuple(out_size)
+        out = torch.empty(B, 3, oh, ow, device=src.device, dtype=out_dtype)
+        u8 = torch.empty(B, oh, ow, 3, device=src.device, dtype=torch.uint8) if want_u8 else None
+        m = (C.c_float * 3)(*[float(v) for v in mean])
+        sd = (C.c_float * 3)(*[float(v) for v in std])
+        _lib.check(lib.mvlpt_preprocess(self.h, _ptr(src), src.numel(), descs, B, oh, ow, m, sd, _ptr(out), _TORCH2DT[out_dtype],
+                                        _ptr(u8), _stream()), self.h, "preprocess")
+        return (out, u8) if want_u8 else out
+
     # ------------------------------------------------------------------ profiling
     def profile_begin(self, all_kernels: bool = False):
         _lib.check(lib.mvlpt_profile_begin(self.h, int(all_kernels)), self.h, "profile_begin")

@@ -250,13 +250,66 @@ def make_metrics():
     print("[golden] metrics:", {k: float(v) for k, v in out.items() if k.endswith(("accuracy", "class", "map11", "auc"))})
 
 
+def make_preprocess():
+    """Input pipeline fixtures: Pillow's own `crop` + `resize(BICUBIC)` (the arithmetic behind torchvision's
+    RandomResizedCrop / Resize on PIL images: configs/trainers/MVLPT/vit_b16.yaml:8-13, feature.py:538-553) followed by
+    ToTensor (u8 -> fp32 / 255) and Normalize with the CLIP mean/std, computed with torch CPU ops.  Data only."""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073])           # vit_b16.yaml:11-12
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711])
+    out = {"mean": mean.numpy(), "std": std.numpy()}
+    # (H, W, crop(top,left,h,w), resized (rh,rw), window (top,left,h,w), flip, content)
+    specs = [
+        (60, 80, (7, 5, 40, 50), (32, 32), (0, 0, 32, 32), 0, "noise"),        # downscale both ways
+        (60, 80, (0, 0, 60, 80), (32, 32), (0, 0, 32, 32), 1, "smooth"),       # whole image, flipped
+        (20, 24, (2, 3, 11, 13), (32, 32), (0, 0, 32, 32), 0, "noise"),        # upscale
+        (48, 64, (8, 16, 32, 40), (32, 32), (0, 0, 32, 32), 1, "binary"),      # height unchanged: vertical pass skipped
+        (64, 48, (10, 4, 50, 32), (32, 32), (0, 0, 32, 32), 0, "smooth"),      # width unchanged: horizontal pass skipped
+        (40, 40, (4, 4, 32, 32), (32, 32), (0, 0, 32, 32), 1, "noise"),        # no resize at all
+        (96, 130, (0, 0, 96, 130), (36, 48), (2, 8, 32, 32), 0, "smooth"),     # Resize(36) + CenterCrop(32) (eval path)
+        (33, 200, (0, 0, 33, 200), (32, 193), (0, 80, 32, 32), 0, "noise"),    # extreme aspect, centre window
+        (7, 9, (1, 1, 5, 7), (32, 32), (0, 0, 32, 32), 0, "binary"),           # tiny source, clamped taps
+        (300, 400, (37, 91, 213, 251), (224, 224), (0, 0, 224, 224), 1, "smooth"),   # full-size output
+        (1, 50, (0, 3, 1, 40), (32, 32), (0, 0, 32, 32), 0, "noise"),          # one-row source
+    ]
+    for i, (H, W, (ct, cl, ch, cw), (rh, rw), (ot, ol, oh, ow), flip, kind) in enumerate(specs):
+        if kind == "noise":
+            a = rng.integers(0, 256, (H, W, 3))
+        elif kind == "binary":
+            a = rng.integers(0, 2, (H, W, 3)) * 255
+        else:
+            yy, xx = np.mgrid[0:H, 0:W]
+            a = np.stack([127 + 120 * np.sin(yy / 7.0 + xx / 11.0), (xx * 255) // max(W - 1, 1),
+                          127 + 100 * np.cos(yy / 3.0) * np.sin(xx / 5.0)], -1) + rng.integers(-6, 7, (H, W, 3))
+        a = np.clip(a, 0, 255).astype(np.uint8)
+        img = Image.fromarray(a).crop((cl, ct, cl + cw, ct + ch)).resize((rw, rh), Image.BICUBIC)     # PIL: (width, height)
+        img = img.crop((ol, ot, ol + ow, ot + oh))
+        if flip:
+            img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        u8 = np.asarray(img).copy()
+        tens = torch.from_numpy(u8).permute(2, 0, 1).contiguous().to(torch.float32).div(255)           # ToTensor
+        tens = (tens - mean[:, None, None]) / std[:, None, None]                                        # Normalize
+        out[f"c{i}_src"] = a
+        out[f"c{i}_desc"] = np.array([ct, cl, ch, cw, rh, rw, ot, ol, oh, ow, flip], dtype=np.int64)
+        out[f"c{i}_u8"] = u8
+        out[f"c{i}_f32"] = tens.numpy()
+    out["n"] = np.int64(len(specs))
+    np.savez_compressed(os.path.join(OUT, "preprocess.npz"), **out)
+    print("[golden] preprocess:", len(specs), "cases,", os.path.getsize(os.path.join(OUT, "preprocess.npz")) // 1024, "KiB")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if set(sys.argv[1:]) == {"preprocess"}:
+        return make_preprocess()
     which = set(sys.argv[1:]) or {"tiny", "full", "tokens", "metrics"}
     if which == {"metrics"}:
         return make_metrics()
     if "metrics" in which:
         make_metrics()
+    if "preprocess" in which or not sys.argv[1:]:
+        make_preprocess()
     torch.set_num_threads(8)
     mv, cm = ref_shim.load_reference()
     if "tokens" in which:
