@@ -8,7 +8,14 @@ OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result
 LIB   := mvlpt_amd/libmvlpt_hip.so
 
-all: $(LIB)
+ORACLE_SO := oracle/_build/libresample_oracle.so
+
+all: $(LIB) $(ORACLE_SO)
+
+# CPU oracle of the input pipeline (test infrastructure only: never linked into $(LIB))
+$(ORACLE_SO): oracle/resample_oracle.c
+	@mkdir -p oracle/_build
+	gcc -O2 -ffp-contract=off -shared -fPIC -o $@ $< -lm
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/attn_common.h include/mvlpt_hip.h
 	@mkdir -p $(OBJDIR)
@@ -18,6 +25,6 @@ $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
 clean:
-	rm -rf build $(LIB)
+	rm -rf build $(LIB) oracle/_build
 
 .PHONY: all clean

@@ -9,6 +9,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64; it must be loaded FIRST so that libmvlpt_hip.so binds to
+# the same HIP runtime instance (two runtimes in one process do not see each other's devices, streams or pointers).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvlpt_hip.so")
 
