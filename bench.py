@@ -151,6 +151,26 @@ def main():
         nxt = dm.train_loader_x[(i + 1) % n_batches] if nonlocal_pipeline else None
         return trainer.forward_backward(dm.train_loader_x[i % n_batches], next_batch=nxt)
 
+    # Multi-rank runs: make sure the cross-step prefetch is a win on this system before the timed region (it changes
+    # how the gradient all-reduce interleaves with the side streams).  Untimed probe, 3 steps per mode, the decision is
+    # the same on every rank (MAX over ranks of each mode's time).
+    if pipeline and world > 1:
+        def probe(flag):
+            nonlocal pipeline
+            pipeline = flag
+            step(0)
+            torch.cuda.synchronize(); D.barrier()
+            t = time.perf_counter()
+            for i in range(3):
+                step(i)
+            torch.cuda.synchronize()
+            return D.all_reduce_max(time.perf_counter() - t, dev)
+        t_pipe, t_plain = probe(True), probe(False)
+        pipeline = t_pipe <= 1.15 * t_plain       # only a clear loss switches it off (3-step probes are noisy)
+        if rank == 0 and not pipeline:
+            print(f"note: cross-step prefetch disabled (probe: {t_pipe / 3 * 1e3:.2f} ms/step with, {t_plain / 3 * 1e3:.2f} without)",
+                  file=sys.stderr)
+
     for i in range(args.warmup):
         out = step(i)
     torch.cuda.synchronize()

@@ -15,9 +15,17 @@ import torch
 import torch.distributed as dist
 
 
+def _share_one_gpu() -> bool:
+    """MVLPT_DEBUG_SHARE_GPU=1: every rank uses cuda:0 and the collectives go through gloo — lets the N > 1 code path
+    (rendezvous, broadcast, gradient all-reduce, class sharding, bench timing protocol) be exercised with the real HIP
+    engine on a ONE-GPU box.  Debug aid only: RCCL cannot place two ranks on one device."""
+    return os.environ.get("MVLPT_DEBUG_SHARE_GPU", "0") == "1"
+
+
 def rank_info() -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from the torchrun environment (1 process when absent)."""
-    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    local = 0 if _share_one_gpu() else int(os.environ.get("LOCAL_RANK", 0))
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), local
 
 
 def init_process_group(backend: str | None = None) -> Tuple[int, int, int]:
@@ -26,7 +34,7 @@ def init_process_group(backend: str | None = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = "nccl" if (torch.cuda.is_available() and not _share_one_gpu()) else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
