@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < MAXQ; ++i) pre[i] = load_ops(wave + 4 * i);
   }
-  stage_rows_dma<T>(sK, base + d, ld, L, LP, wave, lane, a.flags & 1);
-  stage_rows_dma<T>(sV, base + 2 * d, ld, L, LP, wave, lane, a.flags & 1);
+  stage_rows_dma<T>(sK, base + d, ld, L, LP, wave, lane);
+  stage_rows_dma<T>(sV, base + 2 * d, ld, L, LP, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -304,8 +304,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
     sLse[i] = i < L ? a.lse[((size_t)n * H + h) * L + i] : 0.f;
     sDel[i] = i < L ? a.delta[((size_t)n * H + h) * L + i] : 0.f;
   }
-  stage_rows_dma<T>(sQ, base, ld, L, LP, wave, lane, a.flags & 1);
-  stage_rows_dma<T>(sdO, dob, (size_t)d, L, LP, wave, lane, a.flags & 1);
+  stage_rows_dma<T>(sQ, base, ld, L, LP, wave, lane);
+  stage_rows_dma<T>(sdO, dob, (size_t)d, L, LP, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -438,6 +438,7 @@ static bool use_stream(int L, bool bwd) {
 }
 
 hipError_t launch_attn_fwd(int dtype, const AttnArgs& a_, hipStream_t s) {
+  // bit 0: non-temporal K/V staging (one workgroup reads them once), bit 1: non-temporal output stores  (+0.5 % on the step)
   static const int flags = [] { const char* e = getenv("MVLPT_ATTN_FLAGS"); return e ? atoi(e) : 3; }();
   AttnArgs a = a_;
   a.flags = flags;
@@ -448,10 +449,7 @@ hipError_t launch_attn_fwd(int dtype, const AttnArgs& a_, hipStream_t s) {
   if (dtype == DT_BF16) return a.causal ? fwd_n<bf16, true>(nkt, a, s) : fwd_n<bf16, false>(nkt, a, s);
   return hipErrorInvalidValue;
 }
-hipError_t launch_attn_bwd(int dtype, const AttnBwdArgs& a_, hipStream_t s) {
-  static const int flags = [] { const char* e = getenv("MVLPT_ATTNB_FLAGS"); return e ? atoi(e) : 0; }();
-  AttnBwdArgs a = a_;
-  a.flags = flags;
+hipError_t launch_attn_bwd(int dtype, const AttnBwdArgs& a, hipStream_t s) {
   if (a.L <= 0 || a.L > attn_max_len() || a.N <= 0) return hipErrorInvalidValue;
   if (use_stream(a.L, true)) return launch_attn_bwd_stream(dtype, a, s);
   const int nkt = nkt_for(a.L);

@@ -129,10 +129,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
         const size_t o = (size_t)m * N + nbase + c * 4;
         if constexpr (EPI == EPI_RESID32) {
           v += rv[i][it];
-          if (m < M) {
-            if (g.cached_out) *(f32x4*)((float*)g.out + o) = v;
-            else __builtin_nontemporal_store(v, (f32x4*)((float*)g.out + o));
-          }
+          if (m < M) __builtin_nontemporal_store(v, (f32x4*)((float*)g.out + o));
         } else if constexpr (EPI == EPI_GELUBWD) {
           v4 w;
 #pragma unroll
@@ -623,11 +620,8 @@ hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hip
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N % 128) != 0) return hipErrorInvalidValue;
   if (epi == EPI_RESID32 && !g.resid) return hipErrorInvalidValue;
   if (epi == EPI_GELUBWD && !g.aux) return hipErrorInvalidValue;
-  static const int resid_cached = [] { const char* e = getenv("MVLPT_RESID_CACHED"); return e ? atoi(e) : 0; }();
-  GemmArgs gg = g;
-  if (epi == EPI_RESID32) gg.cached_out = resid_cached;
-  if (dtype == DT_F16) return launch_epi<f16>(gg, epi, s, ea, eb);
-  if (dtype == DT_BF16) return launch_epi<bf16>(gg, epi, s, ea, eb);
+  if (dtype == DT_F16) return launch_epi<f16>(g, epi, s, ea, eb);
+  if (dtype == DT_BF16) return launch_epi<bf16>(g, epi, s, ea, eb);
   return hipErrorInvalidValue;
 }
 

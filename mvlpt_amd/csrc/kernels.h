@@ -22,7 +22,6 @@ struct GemmArgs {
   const float* resid;  // [M,N] fp32   (EPI_RESID32)
   void* out;           // [M,N]
   void* out2;          // [M,N] 16-bit, optional (EPI_GELU)
-  int cached_out = 0;  // EPI_RESID32: 1 = ordinary (cache-allocating) stores of the fp32 output instead of non-temporal
 };
 // ev_start/ev_stop (optional): recorded by the dispatch itself (hipExtLaunchKernelGGL): kernel-exact timing with no
 // extra marker packets on the stream.
@@ -68,7 +67,6 @@ struct AttnBwdArgs {
   const void* qkv; const void* out; const void* dout; const float* lse;
   float* delta /*[N*H*L] scratch*/; void* dqkv /*[N*L,3d]*/;
   int N, L, H; int causal;
-  int flags = 0;    // 1 = non-temporal staging of the operands
 };
 hipError_t launch_attn_bwd(int dtype, const AttnBwdArgs& a, hipStream_t s);
 int attn_max_len();

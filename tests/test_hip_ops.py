@@ -67,11 +67,13 @@ def test_gemm_epilogues(dtype):
     assert relerr(outg, acc * O.quick_gelu_grad(u.float())) < TOL[dtype]
 
 
-@pytest.mark.parametrize("d", [128, 512, 768, 1024])
-def test_layernorm_fwd_bwd(d):
+@pytest.mark.parametrize("d,rows", [(128, 203), (512, 203), (768, 203), (1024, 203),
+                                    # >= 4096 rows: the grid-stride kernels (next-row prefetch; 8192 rows in flight on 256 CUs,
+                                    # so 20011 rows make every wave loop 2-3 times and end on a ragged tail)
+                                    (512, 4099), (768, 20011), (1024, 9000), (1280, 4500)])
+def test_layernorm_fwd_bwd(d, rows):
     E = _eng()
     g = torch.Generator().manual_seed(d)
-    rows = 203
     x = torch.randn(rows, d, generator=g) * 3 + 0.5
     gamma = 1 + 0.1 * torch.randn(d, generator=g)
     beta = 0.1 * torch.randn(d, generator=g)
