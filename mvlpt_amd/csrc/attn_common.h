@@ -61,6 +61,19 @@ __device__ __forceinline__ typename Vec<T>::v8 frag_vt(const char* img, int kb, 
   for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[e + 4] = hi[e]; }
   return r;
 }
+// same for a 32-key block whose SECOND 16-key tile does not exist (odd tile count): the upper k-slots re-read the first
+// tile (finite values) and must meet P = 0
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::v8 frag_vt_half(const char* img, int kb, int dt, int fr, int fg) {
+  const int koff = fg * 4 + (fr >> 2);
+  const int chunk = (dt * 2 + ((fr & 3) >> 1)) ^ (koff & 7);
+  const char* p = img + (kb * 32 + koff) * 128 + chunk * 16 + (fr & 1) * 8;
+  const typename Vec<T>::v4 lo = tr_read4<T>(p);
+  typename Vec<T>::v8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[e + 4] = lo[e]; }
+  return r;
+}
 __device__ __forceinline__ float quad_sum(float v) {  // reduce over the four lanes sharing lane&15
   v += __shfl_xor(v, 16, 64);
   v += __shfl_xor(v, 32, 64);
