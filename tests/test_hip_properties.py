@@ -182,3 +182,27 @@ def test_gradient_is_a_descent_direction_at_full_size(method):
     drop = float(loss0.detach()) - float(loss1)
     assert drop > 0, f"loss did not go down: {float(loss0):.6f} -> {float(loss1):.6f}"
     assert 0.5 * predicted < drop < 1.5 * predicted, f"first-order prediction {predicted:.3e} vs actual drop {drop:.3e}"
+
+
+@pytest.mark.parametrize("method,B", [("coop", 256), ("upt", 64)])
+def test_step_is_bitwise_deterministic(method, B):
+    """No atomics with order-dependent results, no run-to-run variation from the multi-stream overlap: two identical
+    steps give identical logits, loss and prompt gradients, bit for bit."""
+    arch, model = _model(method, C=100, n_ctx=16 if method == "coop" else 4, n_vpt=4)
+    x = _images(arch, B)
+    y = torch.randint(0, 100, (B,), generator=torch.Generator().manual_seed(9)).cuda()
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        logits = model(x)
+        loss = model.cross_entropy(logits, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().clone(), loss.detach().clone(), _grads(model)
+
+    l0, s0, g0 = run()
+    for _ in range(3):
+        l1, s1, g1 = run()
+        assert torch.equal(l0, l1) and torch.equal(s0, s1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
