@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmvlpt_hip.so")
+LIB_PATH = os.environ.get("MVLPT_HIP_LIB") or os.path.join(_HERE, "libmvlpt_hip.so")   # override: A/B builds of the same ABI
 
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 LABEL_INT64, LABEL_PROB_F32 = 0, 1

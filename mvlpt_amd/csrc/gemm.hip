@@ -26,6 +26,12 @@
 namespace mvlpt {
 
 constexpr int BK = 64;
+#ifndef MVLPT_NS2_MODE
+#define MVLPT_NS2_MODE 1
+#endif
+#ifndef MVLPT_NS2_POS
+#define MVLPT_NS2_POS (GROUPS / 2 - 2)   // after the 3rd of 8 MFMA groups; later positions expose the DMA latency (measured)
+#endif
 
 // Epilogue: the MFMA result layout gives every lane 4 consecutive columns of 16 different rows, i.e. 8-byte
 // pieces scattered over 16 rows per store instruction.  With ~0.8 GFLOP per MB of output (short K) the L2
@@ -260,7 +266,11 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
       // ~100 issue cycles, as much per K-stage as the wave's 32 MFMAs; with two waves per SIMD (8-wave geometry)
       // the older wave issues its DMA BEFORE its MFMAs and the younger one AFTER, so on every SIMD one wave
       // multiplies while its partner is busy with the memory pipe instead of both doing the same thing.
-      const bool dma_first = (NW == 4) || (wave < NW / 2);
+      // With a 2-deep ring the DMA issued in this stage is consumed right after the barrier that ends it, so nobody may
+      // issue it at the END of the stage (its whole latency would be exposed): there the younger wave issues in the
+      // MIDDLE of its MFMA groups instead (MVLPT_NS2_MODE 1; 0 = every wave first).
+      const bool dma_first = (NW == 4) || (NS == 2 && MVLPT_NS2_MODE == 0) || (wave < NW / 2);
+      constexpr bool DMA_MID = NS == 2 && MVLPT_NS2_MODE == 1 && NW != 4;
       bool issued = false;
       if (dma_first) issued = issue();
       const char* base = smem + slot * STAGE;
@@ -298,8 +308,9 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
             acc[ai >> 2][ai & 3][j] = mfma16<T>(bfr[ks & 1][j], afr[cur][i], acc[ai >> 2][ai & 3][j]);
           }
         __builtin_amdgcn_sched_barrier(0);
+        if (DMA_MID && sg == (MVLPT_NS2_POS) && !dma_first) issued = issue();
       }
-      if (!dma_first) issued = issue();
+      if (!DMA_MID && !dma_first) issued = issue();
       n_issued += issued ? 1 : 0;
       // the NEXT stage (n_done + 1) must have landed (own loads) before the barrier; younger ones may stay in flight.
       // vmcnt retires in order and counts stores: right after an epilogue the youngest operations are its ST_MIN
