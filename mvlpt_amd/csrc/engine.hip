@@ -678,7 +678,23 @@ int mvlpt_cross_entropy(void* h, const float* logits, const void* labels, int ki
 int mvlpt_op_gemm(int dtype, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
                   const float* resid, void* out, void* out2, mvlpt_stream_t stream) {
   GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
+#ifdef MVLPT_GEMM_TRACE
+  // debug builds: timeline of workgroup 0 -> $MVLPT_GEMM_TRACE_FILE (8 waves x 2048 int64 records)
+  const char* path = getenv("MVLPT_GEMM_TRACE_FILE");
+  long long* tr = nullptr;
+  const size_t tr_bytes = 16 * 2048 * sizeof(long long);
+  if (path) { OPCHK(hipMalloc(&tr, tr_bytes)); OPCHK(hipMemsetAsync(tr, 0, tr_bytes, (hipStream_t)stream)); g.trace = tr; }
+#endif
   OPCHK(launch_gemm(dtype, epi, g, (hipStream_t)stream));
+#ifdef MVLPT_GEMM_TRACE
+  if (path) {
+    std::vector<long long> h(16 * 2048);
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    OPCHK(hipMemcpy(h.data(), tr, tr_bytes, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 1, tr_bytes, f); fclose(f); }
+    (void)hipFree(tr);
+  }
+#endif
   return 0;
 }
 int mvlpt_op_layernorm_fwd(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,

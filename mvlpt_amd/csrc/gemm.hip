@@ -26,6 +26,14 @@
 namespace mvlpt {
 
 constexpr int BK = 64;
+// Debug timeline (tools/gemm_trace.py): -DMVLPT_GEMM_TRACE builds record s_memtime at fixed points of workgroup 0.
+#ifdef MVLPT_GEMM_TRACE
+constexpr int TR_MAX = 2048;
+#define MVLPT_TR(p) do { if (g.trace && blockIdx.x == 0 && lane == 0 && tr_n < TR_MAX) \
+    g.trace[wave * TR_MAX + tr_n++] = ((long long)(p) << 56) | ((long long)__builtin_amdgcn_s_memtime() & 0xffffffffffffffLL); } while (0)
+#else
+#define MVLPT_TR(p) do { } while (0)
+#endif
 #ifndef MVLPT_NS2_MODE
 #define MVLPT_NS2_MODE 1
 #endif
@@ -170,6 +178,9 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
   const int M = g.M, N = g.N, K = g.K;
   const T* __restrict__ A = (const T*)g.A;
   const T* __restrict__ Bt = (const T*)g.Bt;
+#ifdef MVLPT_GEMM_TRACE
+  int tr_n = 0;
+#endif
 
   // XCD-aware order: workgroup b runs on XCD b%8; inside a full round each XCD gets G/8 consecutive tiles
   // (tiles are N-fastest, so neighbours share their A panel in that XCD's L2).
@@ -272,7 +283,8 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
       const bool dma_first = (NW == 4) || (NS == 2 && MVLPT_NS2_MODE == 0) || (wave < NW / 2);
       constexpr bool DMA_MID = NS == 2 && MVLPT_NS2_MODE == 1 && NW != 4;
       bool issued = false;
-      if (dma_first) issued = issue();
+      MVLPT_TR(1);
+      if (dma_first) { issued = issue(); MVLPT_TR(2); }
       const char* base = smem + slot * STAGE;
       // Register-double-buffered fragment pipeline: the ds_reads of MFMA group s+1 (two A fragments, plus the four
       // B fragments when the k-step changes) are issued BEFORE the 8 MFMAs of group s, so hipcc's counted lgkmcnt
@@ -294,6 +306,15 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
 #pragma unroll
       for (int sg = 0; sg < GROUPS; ++sg) {
         const int ks = sg / PAIRS, pair = sg % PAIRS, cur = sg & 1;
+        // The prefetch reads of group sg+1 are placed AFTER the first MFMA of group sg: hipcc waits with lgkmcnt(0)
+        // in front of the first MFMA that needs LDS data, and with the reads in front of it that wait would also
+        // cover the reads just issued (a full LDS round trip in front of every other group).
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const int ai = pair * 2;
+          acc[ai >> 2][ai & 3][0] = mfma16<T>(bfr[ks & 1][0], afr[cur][0], acc[ai >> 2][ai & 3][0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (sg + 1 < GROUPS) {
           const int nks = (sg + 1) / PAIRS, npair = (sg + 1) % PAIRS;
           if (npair == 0) load_b(nks, bfr[nks & 1]);
@@ -304,25 +325,30 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
+            if (i == 0 && j == 0) continue;
             const int ai = pair * 2 + i;
             acc[ai >> 2][ai & 3][j] = mfma16<T>(bfr[ks & 1][j], afr[cur][i], acc[ai >> 2][ai & 3][j]);
           }
         __builtin_amdgcn_sched_barrier(0);
-        if (DMA_MID && sg == (MVLPT_NS2_POS) && !dma_first) issued = issue();
+        if (DMA_MID && sg == (MVLPT_NS2_POS) && !dma_first) { MVLPT_TR(3); issued = issue(); MVLPT_TR(2); }
       }
-      if (!DMA_MID && !dma_first) issued = issue();
+      MVLPT_TR(4);
+      if (!DMA_MID && !dma_first) { issued = issue(); MVLPT_TR(2); }
       n_issued += issued ? 1 : 0;
       // the NEXT stage (n_done + 1) must have landed (own loads) before the barrier; younger ones may stay in flight.
       // vmcnt retires in order and counts stores: right after an epilogue the youngest operations are its ST_MIN
       // global stores followed by the DMA just issued, so allowing ST_MIN + LOADS operations in flight still
       // guarantees the older DMA has landed without making the wave wait for its own output stores (NS == 3 only).
       wait_stage(n_issued - (n_done + 2), stores_pending && NS == 3 && issued);
+      MVLPT_TR(5);
       stores_pending = false;
       ++n_done;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      MVLPT_TR(7);
       slot = slot + 1 == NS ? 0 : slot + 1;
     }
+    MVLPT_TR(8);
     // the slot the load cursor will fill next has just been released by the barrier above: use it as scratch,
     // and fence the scratch reads of all waves against that DMA with one more barrier
     int tm, tn;
@@ -332,6 +358,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
       epilogue_store<T, EPI>(g, acc[hh], tm * BM_ + wm * (WMF * 16) + hh * 64, tn * BN + wn * 64, lane,
                              LinearRows<144>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE},
                              LinearRows<272>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE});
+    MVLPT_TR(9);
     __builtin_amdgcn_s_barrier();
     stores_pending = (tm + 1) * BM_ <= M;
   }

@@ -22,6 +22,9 @@ struct GemmArgs {
   const float* resid;  // [M,N] fp32   (EPI_RESID32)
   void* out;           // [M,N]
   void* out2;          // [M,N] 16-bit, optional (EPI_GELU)
+#ifdef MVLPT_GEMM_TRACE
+  long long* trace = nullptr;   // debug builds only: per-wave (point id << 56 | s_memtime) records of workgroup 0
+#endif
 };
 // ev_start/ev_stop (optional): recorded by the dispatch itself (hipExtLaunchKernelGGL): kernel-exact timing with no
 // extra marker packets on the stream.
