@@ -586,11 +586,14 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   static const int geo = getenv("MVLPT_GEMM_GEO") ? atoi(getenv("MVLPT_GEMM_GEO")) : 2;   // experiment switch (0,1,2)
   // phased 256x128 variant: measured +3..5 % on long-K GEMMs (MLP down-projection, K = 4d), -4..6 % on K = d
   static const int phased = getenv("MVLPT_GEMM_PHASED") ? atoi(getenv("MVLPT_GEMM_PHASED")) : 2;   // 0 off, 1 all, 2 long K
-  if (t128 >= 384 && (phased == 1 || (phased == 2 && g.K >= 2048 && !(g.N % 256 == 0 && t256 >= 1024)))) {
+  // 256x256 needs >= 4 rounds of tiles, or >= 2 rounds when K is long (a ragged last round then costs less than the
+  // smaller geometry's extra LDS traffic: N = 768, K = 3072: 315 -> 297 us with 2.3 rounds)
+  const bool big = g.N % 256 == 0 && (t256 >= 1024 || (t256 >= 512 && g.K >= 2048));
+  if (t128 >= 384 && (phased == 1 || (phased == 2 && g.K >= 2048 && !big))) {
     *tile_m = 256; *tile_n = 128;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_phased<T, EPI>(g, s, ea, eb);
   }
-  if (geo >= 2 && g.N % 256 == 0 && t256 >= 1024) {
+  if (geo >= 2 && big) {
     *tile_m = 256; *tile_n = 256;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
   }
