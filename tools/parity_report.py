@@ -34,13 +34,17 @@ for dt in sys.argv[1:] or ["fp16", "bf16"]:
 from tests.golden_util import FULL_CASES, full_case_inputs
 from mvlpt_amd.weights import ARCHS, make_state_dict
 for dt in sys.argv[1:] or ["fp16"]:
-    for arch_name, cases in (("ViT-B/32", FULL_CASES[:1]), ("ViT-B/16", FULL_CASES[1:])):
+    groups = {}
+    for name in FULL_CASES:
+        arch_name = "ViT-B/32" if "vitb32" in name else ("ViT-L/14@336px" if "vitl14_336" in name else "ViT-B/16")
+        groups.setdefault(arch_name, []).append(name)
+    for arch_name, cases in groups.items():
         sd = make_state_dict(ARCHS[arch_name], 2, include_token_embedding=True)
         clip = FrozenCLIP(sd, compute_dtype=dt)
         for name in cases:
             case = load_npz(name)
-            image, pre, suf = full_case_inputs(case, sd)
-            model = build_model(case, clip, 224, pre, suf)
+            image, pre, suf = full_case_inputs(case, sd, ARCHS[arch_name].image_resolution)
+            model = build_model(case, clip, ARCHS[arch_name].image_resolution, pre, suf)
             dev = clip.device
             logits = model(image.to(dev), task=None)
             loss = model.cross_entropy(logits, t(case["label"]).to(dev))
