@@ -42,3 +42,15 @@ for w, p, t in waves:
     tot = int(t[-1] - t[0])
     desc = "  ".join(f"{a}->{b}: {np.mean(v):7.0f} x{len(v)}" for (a, b), v in sorted(seg.items()))
     print(f"wave {w}: {n_stage} stages, {tot} ticks total, {tot / max(n_stage, 1):.0f} per stage | {desc}")
+
+# vmcnt-wait (4->5) of the FIRST stage after an epilogue vs the other stages (is the wait draining the epilogue's stores?)
+for w, p, t in waves[:1] + waves[4:5]:
+    first, rest, after_epi = [], [], False
+    for k in range(1, len(p)):
+        if p[k - 1] == 9:
+            after_epi = True
+        if p[k - 1] == 4 and p[k] == 5:
+            (first if after_epi else rest).append(int(t[k] - t[k - 1]))
+            after_epi = False
+    if first and rest:
+        print(f"wave {w}: vmcnt wait of a tile's first stage {np.mean(first):.0f} ticks (n={len(first)}) vs {np.mean(rest):.0f} elsewhere")
