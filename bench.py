@@ -89,8 +89,8 @@ def cpu_baseline_images_per_sec(arch, sd, B, C, L, n_ctx, sample_images=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--classes", type=int, default=100)
     ap.add_argument("--arch", default="ViT-B/16")
