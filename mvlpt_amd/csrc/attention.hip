@@ -376,6 +376,91 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
   }
 }
 
+// ======================================================================================= backward, CLS query only
+// Last block of the image tower when it needs a backward (VPT / UPT): only x[:, 0, :] of that block is consumed
+// (trainers/mvlpt.py:88), so only the CLS query carries a gradient.  Per (sequence, head), in fp32, one pass over K and V:
+//   delta = dO.O,  p_j = exp(q.k_j / 8 - lse),  dp_j = dO.v_j,  ds_j = p_j (dp_j - delta) / 8,
+//   dV_j = p_j dO,  dK_j = ds_j q,  dQ_0 = sum_j ds_j k_j,  dQ_{i>0} = 0.
+// Four lanes share a key (16 of the 64 head dimensions each), a wave covers 16 keys, a block 64 keys per sweep.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_cls_kernel(const T* __restrict__ qkv, const T* __restrict__ o_cls,
+                                                           const T* __restrict__ do_cls, const float* __restrict__ lse,
+                                                           T* __restrict__ dqkv, int N, int L, int H) {
+  using v8 = typename Vec<T>::v8;
+  __shared__ float sq[64], sdo[64], red[4][64], sdelta;
+  const int n = blockIdx.x / H, h = blockIdx.x % H, d = H * 64, tid = threadIdx.x;
+  const size_t ld = (size_t)3 * d;
+  const T* base = qkv + (size_t)n * L * ld + h * 64;
+  T* gbase = dqkv + (size_t)n * L * ld + h * 64;
+  if (tid < 64) {
+    sq[tid] = to_f32<T>(base[tid]);
+    const float g = to_f32<T>(do_cls[(size_t)n * d + h * 64 + tid]);
+    sdo[tid] = g;
+    const float v = wave_sum(g * to_f32<T>(o_cls[(size_t)n * d + h * 64 + tid]));
+    if (tid == 0) sdelta = v;
+  }
+  __syncthreads();
+  const float delta = sdelta, l0 = lse[((size_t)n * H + h) * L];
+  const int lane = tid & 63, wave = tid >> 6, kg = lane >> 2, ch = lane & 3;
+  float q16[16], g16[16], dqa[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { q16[e] = sq[ch * 16 + e]; g16[e] = sdo[ch * 16 + e]; dqa[e] = 0.f; }
+  for (int j0 = wave * 16; j0 < L; j0 += 64) {
+    const int j = j0 + kg;
+    const int jc = j < L ? j : L - 1;
+    const T* kp = base + (size_t)jc * ld + d + ch * 16;
+    const v8 k0 = *(const v8*)kp, k1 = *(const v8*)(kp + 8);
+    const v8 v0 = *(const v8*)(kp + d), v1 = *(const v8*)(kp + d + 8);
+    float k16[16], sdot = 0.f, dp = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      k16[e] = to_f32<T>(k0[e]); k16[e + 8] = to_f32<T>(k1[e]);
+      dp += g16[e] * to_f32<T>(v0[e]) + g16[e + 8] * to_f32<T>(v1[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sdot += q16[e] * k16[e];
+    sdot += __shfl_xor(sdot, 1, 64); sdot += __shfl_xor(sdot, 2, 64);
+    dp += __shfl_xor(dp, 1, 64); dp += __shfl_xor(dp, 2, 64);
+    const float pj = j < L ? __expf(sdot * 0.125f - l0) : 0.f;
+    const float ds = pj * (dp - delta) * 0.125f;
+    v8 wk[2], wv[2], wz[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      dqa[e] += ds * k16[e];
+      wk[e >> 3][e & 7] = from_f32<T>(ds * q16[e]);
+      wv[e >> 3][e & 7] = from_f32<T>(pj * g16[e]);
+      wz[e >> 3][e & 7] = from_f32<T>(0.f);
+    }
+    if (j < L) {
+      T* gp = gbase + (size_t)j * ld + ch * 16;
+      if (j > 0) { *(v8*)gp = wz[0]; *(v8*)(gp + 8) = wz[1]; }            // dQ of the other queries
+      *(v8*)(gp + d) = wk[0]; *(v8*)(gp + d + 8) = wk[1];
+      *(v8*)(gp + 2 * d) = wv[0]; *(v8*)(gp + 2 * d + 8) = wv[1];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    float v = dqa[e];
+    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if (kg == 0) red[wave][ch * 16 + e] = v;
+  }
+  __syncthreads();
+  if (tid < 64) gbase[tid] = from_f32<T>(red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
+hipError_t launch_attn_bwd_cls(int dtype, const void* qkv, const void* o_cls, const void* do_cls, const float* lse, void* dqkv,
+                               int N, int L, int H, hipStream_t s) {
+  if (N <= 0 || L <= 0 || H <= 0) return hipErrorInvalidValue;
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL(attn_bwd_cls_kernel<f16>, dim3(N * H), dim3(256), 0, s, (const f16*)qkv, (const f16*)o_cls, (const f16*)do_cls, lse,
+                       (f16*)dqkv, N, L, H);
+  else if (dtype == DT_BF16)
+    hipLaunchKernelGGL(attn_bwd_cls_kernel<bf16>, dim3(N * H), dim3(256), 0, s, (const bf16*)qkv, (const bf16*)o_cls, (const bf16*)do_cls,
+                       lse, (bf16*)dqkv, N, L, H);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 // ======================================================================================= launchers
 template <typename T, int NKT, bool CAUSAL>
 static hipError_t fwd_t(const AttnArgs& a, hipStream_t s) {

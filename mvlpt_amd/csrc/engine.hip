@@ -89,6 +89,9 @@ struct Engine {
   // vision fwd extras (carved from vis_ws)
   int vB = 0, v_nvpt = 0, v_ndeep = 0; float* cls32 = nullptr; float* dcls32 = nullptr;
   float* xc32 = nullptr; void *ac16 = nullptr, *hc16 = nullptr, *gc16 = nullptr;   // CLS-only last layer (compact [B,·])
+  // ... and what its backward needs (VPT / UPT): saved LN inputs, pre-GELU, and the compact gradient buffers
+  bool v_cls_last = false; float *xcm32 = nullptr, *xco32 = nullptr, *dxc32 = nullptr, *dhc32 = nullptr;
+  void *uc16 = nullptr, *duc16 = nullptr, *dxc16 = nullptr, *dOc16 = nullptr;
   // text fwd extras
   int tC = 0, tL = 0, t_nctx = 0, t_per_class = 0; int32_t* eot_rows = nullptr; int32_t* ctx_pos = nullptr;
   float* eot32 = nullptr; float* deot32 = nullptr;
@@ -453,7 +456,7 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   const bool save = save_for_bwd != 0;
   const size_t npatch = (size_t)B * G2;
   size_t need = tower_bytes(E->vis, B, Lv, save) + align256(npatch * E->Kp * 2) + align256(npatch * dv * 4) +
-                3 * align256((size_t)B * dv * 4) + 2 * align256((size_t)B * dv * 2) + align256((size_t)B * dv * 8) + 4096;
+                7 * align256((size_t)B * dv * 4) + 4 * align256((size_t)B * dv * 2) + 3 * align256((size_t)B * dv * 8) + 4096;
   E->vs.valid = false;
   HIPCHK(E, E->vis_ws.reserve(need));
   Bump bp; bp.base = (char*)E->vis_ws.p; bp.cap = E->vis_ws.cap;
@@ -464,6 +467,11 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   E->xc32 = bp.take<float>((size_t)B * dv);
   E->ac16 = bp.take_bytes((size_t)B * dv * 2); E->hc16 = bp.take_bytes((size_t)B * dv * 2);
   E->gc16 = bp.take_bytes((size_t)B * dv * 4 * 2);
+  E->xcm32 = bp.take<float>((size_t)B * dv); E->xco32 = bp.take<float>((size_t)B * dv);
+  E->dxc32 = bp.take<float>((size_t)B * dv); E->dhc32 = bp.take<float>((size_t)B * dv);
+  E->dxc16 = bp.take_bytes((size_t)B * dv * 2); E->dOc16 = bp.take_bytes((size_t)B * dv * 2);
+  E->uc16 = bp.take_bytes((size_t)B * dv * 4 * 2); E->duc16 = bp.take_bytes((size_t)B * dv * 4 * 2);
+  E->v_cls_last = false;
   carve_tower(bp, E->vis, E->vs, B, Lv, save, false);
   TowerState& st = E->vs;
   E->vB = B; E->v_nvpt = n_vpt; E->v_ndeep = n_deep;
@@ -488,32 +496,36 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
         continue;
       }
     }
-    if (l == E->vis.layers - 1 && !save) { cls_only_last = true; break; }
+    if (l == E->vis.layers - 1) { cls_only_last = true; break; }
     if (int rc = block_fwd(E, E->vis, st, l, s)) return rc;
   }
   if (cls_only_last) {
-    // Only x[:, 0, :] of the last block is consumed (trainers/mvlpt.py:88) and, with no backward to feed, nothing
-    // else of it is observable: keys/values are still needed for every token, but queries, out-proj, ln_2 and the
-    // MLP are evaluated for the CLS row only (B rows instead of B*Lv: ~20/24 of the layer's GEMM FLOPs vanish).
+    // Only x[:, 0, :] of the last block is consumed (trainers/mvlpt.py:88): keys/values are still needed for every
+    // token, but queries, out-proj, ln_2 and the MLP are evaluated for the CLS row only (B rows instead of B*Lv: ~20/24
+    // of the layer's GEMM FLOPs vanish) — in the forward and, when the tower has a backward, in the backward as well
+    // (mvlpt_image_bwd: only the CLS query carries a gradient into this block's attention).
     const int l = E->vis.layers - 1;
     const Block& Bk = E->vis.blocks[l];
     const int T = B * Lv;
     float* xin = st.x[2 * l];
+    float* xmid = save ? E->xcm32 : E->xc32;     // kept for the backward: LN2 input ...
+    float* xout = save ? E->xco32 : E->xc32;     // ... and ln_post input
+    E->v_cls_last = save;
     HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dv, s));
     HIPCHK(E, gemm(E, EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dv, dv, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s));
     {
-      AttnArgs a{st.qkv[l], st.attn[l], nullptr, st.N, st.L, st.H, 0, 1};
+      AttnArgs a{st.qkv[l], st.attn[l], save ? st.lse[l] : nullptr, st.N, st.L, st.H, 0, 1};
       ProfScope ps(E, s, PC_ATTN_FWD, 4.0 * st.L * 64.0 * st.N * st.H, (double)T * dv * 2.0 * 2.0);
       HIPCHK(E, launch_attn_fwd(E->dt, a, s));
     }
     { ProfScope ps(E, s, PC_GLUE, 0, (double)B * dv * 12.0);
       HIPCHK(E, hipMemcpy2DAsync(E->ac16, (size_t)dv * 2, st.attn[l], (size_t)Lv * dv * 2, (size_t)dv * 2, B, hipMemcpyDeviceToDevice, s));
       HIPCHK(E, hipMemcpy2DAsync(E->xc32, (size_t)dv * 4, xin, (size_t)Lv * dv * 4, (size_t)dv * 4, B, hipMemcpyDeviceToDevice, s)); }
-    HIPCHK(E, gemm(E, EPI_RESID32, E->ac16, Bk.o.w, B, dv, dv, Bk.o.b, nullptr, E->xc32, E->xc32, nullptr, s));
-    HIPCHK(E, ln_fwd(E, E->dt, E->xc32, nullptr, 1, Bk.ln2, E->hc16, B, dv, s));
-    HIPCHK(E, gemm(E, EPI_GELU, E->hc16, Bk.fc.w, B, 4 * dv, dv, Bk.fc.b, nullptr, nullptr, E->gc16, nullptr, s));
-    HIPCHK(E, gemm(E, EPI_RESID32, E->gc16, Bk.pr.w, B, dv, 4 * dv, Bk.pr.b, nullptr, E->xc32, E->xc32, nullptr, s));
-    HIPCHK(E, ln_fwd(E, DT_F32, E->xc32, nullptr, 1, E->ln_post, E->cls32, B, dv, s));
+    HIPCHK(E, gemm(E, EPI_RESID32, E->ac16, Bk.o.w, B, dv, dv, Bk.o.b, nullptr, E->xc32, xmid, nullptr, s));
+    HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, Bk.ln2, E->hc16, B, dv, s));
+    HIPCHK(E, gemm(E, EPI_GELU, E->hc16, Bk.fc.w, B, 4 * dv, dv, Bk.fc.b, nullptr, nullptr, E->gc16, save ? E->uc16 : nullptr, s));
+    HIPCHK(E, gemm(E, EPI_RESID32, E->gc16, Bk.pr.w, B, dv, 4 * dv, Bk.pr.b, nullptr, xmid, xout, nullptr, s));
+    HIPCHK(E, ln_fwd(E, DT_F32, xout, nullptr, 1, E->ln_post, E->cls32, B, dv, s));
   } else
   // ln_post on the CLS row, then @ proj   (trainers/mvlpt.py:88-91)
   HIPCHK(E, ln_fwd(E, DT_F32, st.x[2 * E->vis.layers], nullptr, Lv, E->ln_post, E->cls32, B, dv, s));
@@ -537,10 +549,36 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
     HIPCHK(E, launch_sgemm_bt(dfeat, E->vproj, E->dcls32, B, dv, e, st.scale_dev, s)); }
   { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 4.0);
     HIPCHK(E, launch_zero(st.dx32, T * dv * 4, s)); }
-  HIPCHK(E, ln_bwd(E, E->dcls32, DT_F32, st.x[2 * st.layers], nullptr, Lv, E->ln_post, nullptr, st.dx32, nullptr, B, dv, s));
-  { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 6.0);
-    HIPCHK(E, launch_cast_f32_to16(E->dt, st.dx32, st.dx16, T * dv, nullptr, s)); }
-  for (int l = st.layers - 1; l >= 0; --l) {
+  int l_top = st.layers - 1;
+  if (E->v_cls_last) {
+    // last block, CLS rows only (see mvlpt_image_fwd): ln_post, MLP, ln_2, out-proj on B compact rows; the attention
+    // backward of a single query per head; then the full-width QKV^T GEMM and ln_1 (keys / values of every token)
+    const int l = st.layers - 1;
+    const Block& Bk = E->vis.blocks[l];
+    const int Ti = (int)T;
+    HIPCHK(E, ln_bwd(E, E->dcls32, DT_F32, E->xco32, nullptr, 1, E->ln_post, nullptr, E->dxc32, E->dxc16, B, dv, s));
+    HIPCHK(E, gemm(E, EPI_GELUBWD, E->dxc16, Bk.pr.wt, B, 4 * dv, dv, nullptr, E->uc16, nullptr, E->duc16, nullptr, s));
+    HIPCHK(E, gemm(E, EPI_STORE32, E->duc16, Bk.fc.wt, B, dv, 4 * dv, nullptr, nullptr, nullptr, E->dhc32, nullptr, s));
+    HIPCHK(E, ln_bwd(E, E->dhc32, DT_F32, E->xcm32, nullptr, 1, Bk.ln2, E->dxc32, E->dxc32, E->dxc16, B, dv, s));
+    HIPCHK(E, gemm(E, EPI_STORE16, E->dxc16, Bk.o.wt, B, dv, dv, nullptr, nullptr, nullptr, E->dOc16, nullptr, s));
+    { ProfScope ps(E, s, PC_ATTN_BWD, 10.0 * st.L * 64.0 * st.N * st.H, (double)T * dv * 2.0 * 5.0);
+      HIPCHK(E, launch_attn_bwd_cls(E->dt, st.qkv[l], E->ac16, E->dOc16, st.lse[l], st.dqkv16, st.N, st.L, st.H, s)); }
+    { ProfScope ps(E, s, PC_GLUE, 0, (double)B * dv * 8.0);      // residual path: d(block input) of the CLS rows
+      HIPCHK(E, hipMemcpy2DAsync(st.dx32, (size_t)Lv * dv * 4, E->dxc32, (size_t)dv * 4, (size_t)dv * 4, B, hipMemcpyDeviceToDevice, s)); }
+    HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, Bk.qkv.wt, Ti, dv, 3 * dv, nullptr, nullptr, nullptr, st.dh32, nullptr, s));
+    HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, Bk.ln1, st.dx32, st.dx32, st.dx16, Ti, dv, s));
+    if (l > 0 && E->v_ndeep > 0 && l <= E->v_ndeep) {
+      ProfScope ps(E, s, PC_GLUE, 0, (double)B * n * dv * 10.0);
+      HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt_deep + (size_t)(l - 1) * n * dv,
+                                          st.scale_dev, 1, s));
+    }
+    l_top = l - 1;
+  } else {
+    HIPCHK(E, ln_bwd(E, E->dcls32, DT_F32, st.x[2 * st.layers], nullptr, Lv, E->ln_post, nullptr, st.dx32, nullptr, B, dv, s));
+    { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 6.0);
+      HIPCHK(E, launch_cast_f32_to16(E->dt, st.dx32, st.dx16, T * dv, nullptr, s)); }
+  }
+  for (int l = l_top; l >= 0; --l) {
     if (st.skip[l]) continue;
     if (int rc = block_bwd(E, E->vis, st, l, s)) return rc;
     if (l > 0 && E->v_ndeep > 0 && l <= E->v_ndeep) {

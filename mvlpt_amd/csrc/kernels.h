@@ -73,6 +73,9 @@ struct AttnBwdArgs {
 };
 hipError_t launch_attn_bwd(int dtype, const AttnBwdArgs& a, hipStream_t s);
 int attn_max_len();
+// backward when only query 0 of every sequence carries a gradient: o_cls / do_cls are compact [N, H*64] rows
+hipError_t launch_attn_bwd_cls(int dtype, const void* qkv, const void* o_cls, const void* do_cls, const float* lse, void* dqkv,
+                               int N, int L, int H, hipStream_t s);
 // streaming variants (attention_stream.hip): any L, 32 KiB LDS ring; launch_attn_* picks between the two families
 hipError_t launch_attn_fwd_stream(int dtype, const AttnArgs& a, hipStream_t s);
 hipError_t launch_attn_bwd_stream(int dtype, const AttnBwdArgs& a, hipStream_t s);
