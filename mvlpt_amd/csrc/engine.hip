@@ -94,6 +94,9 @@ struct Engine {
   void *uc16 = nullptr, *duc16 = nullptr, *dxc16 = nullptr, *dOc16 = nullptr;
   // text fwd extras
   int tC = 0, tL = 0, t_nctx = 0, t_per_class = 0; int32_t* eot_rows = nullptr; int32_t* ctx_pos = nullptr;
+  // EOT-only last text block (compact [C,·] rows; the text-side twin of the CLS-only last image block)
+  bool t_eot_last = false; float *txc32 = nullptr, *txm32 = nullptr, *txo32 = nullptr, *tdxc32 = nullptr, *tdhc32 = nullptr;
+  void *tac16 = nullptr, *thc16 = nullptr, *tgc16 = nullptr, *tuc16 = nullptr, *tduc16 = nullptr, *tdxc16 = nullptr, *tdOc16 = nullptr;
   float* eot32 = nullptr; float* deot32 = nullptr;
   // head state
   int hB = 0, hC = 0; float h_scale = 0.f; const int32_t *h_lo = nullptr, *h_hi = nullptr;
@@ -609,8 +612,8 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
   hipStream_t s = (hipStream_t)stream;
   const int dtw = A.text_width, e = A.embed_dim;
   const bool save = save_for_bwd != 0;
-  size_t need = tower_bytes(E->txt, C, L, save) + 2 * align256((size_t)C * dtw * 4) +
-                align256((size_t)C * 4) + align256((size_t)C * (n_ctx > 0 ? n_ctx : 1) * 4) + 4096;
+  size_t need = tower_bytes(E->txt, C, L, save) + 7 * align256((size_t)C * dtw * 4) + 4 * align256((size_t)C * dtw * 2) +
+                3 * align256((size_t)C * dtw * 8) + align256((size_t)C * 4) + align256((size_t)C * (n_ctx > 0 ? n_ctx : 1) * 4) + 4096;
   E->ts.valid = false;
   HIPCHK(E, E->txt_ws.reserve(need));
   Bump bp; bp.base = (char*)E->txt_ws.p; bp.cap = E->txt_ws.cap;
@@ -618,6 +621,12 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
   E->deot32 = bp.take<float>((size_t)C * dtw);
   E->eot_rows = bp.take<int32_t>(C);
   E->ctx_pos = bp.take<int32_t>((size_t)C * (n_ctx > 0 ? n_ctx : 1));
+  E->txc32 = bp.take<float>((size_t)C * dtw); E->txm32 = bp.take<float>((size_t)C * dtw); E->txo32 = bp.take<float>((size_t)C * dtw);
+  E->tdxc32 = bp.take<float>((size_t)C * dtw); E->tdhc32 = bp.take<float>((size_t)C * dtw);
+  E->tac16 = bp.take_bytes((size_t)C * dtw * 2); E->thc16 = bp.take_bytes((size_t)C * dtw * 2);
+  E->tdxc16 = bp.take_bytes((size_t)C * dtw * 2); E->tdOc16 = bp.take_bytes((size_t)C * dtw * 2);
+  E->tgc16 = bp.take_bytes((size_t)C * dtw * 8); E->tuc16 = bp.take_bytes((size_t)C * dtw * 8); E->tduc16 = bp.take_bytes((size_t)C * dtw * 8);
+  E->t_eot_last = false;
   carve_tower(bp, E->txt, E->ts, C, L, save, true);
   TowerState& st = E->ts;
   E->tC = C; E->tL = L; E->t_nctx = n_ctx; E->t_per_class = ctx_per_class;
@@ -625,9 +634,33 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
     HIPCHK(E, launch_assemble_prompts(prefix, suffix, ctx, ctx_per_class, n_ctx, layout, E->tpos, st.x[0], C, L, dtw, s));
     HIPCHK(E, launch_eot_rows(eot, E->eot_rows, C, L, s));
     if (save && n_ctx > 0) HIPCHK(E, launch_build_ctx_pos(layout, E->ctx_pos, C, L, n_ctx, s)); }
-  for (int l = 0; l < E->txt.layers; ++l)
+  for (int l = 0; l + 1 < E->txt.layers; ++l)
     if (int rc = block_fwd(E, E->txt, st, l, s)) return rc;
-  HIPCHK(E, ln_fwd(E, DT_F32, st.x[2 * E->txt.layers], E->eot_rows, 1, E->ln_final, E->eot32, C, dtw, s));
+  {
+    // Only x[c, eot_c] of the last block is consumed (trainers/mvlpt.py:126-128): LN1, QKV and the attention run for every
+    // position (keys / values), then out-proj, ln_2, the MLP and ln_final run on the C gathered EOT rows — forward and,
+    // in mvlpt_text_bwd, backward.
+    const int l = E->txt.layers - 1;
+    const Block& Bk = E->txt.blocks[l];
+    const int T = C * L;
+    float* xin = st.x[2 * l];
+    E->t_eot_last = save;
+    HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dtw, s));
+    HIPCHK(E, gemm(E, EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dtw, dtw, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s));
+    {
+      AttnArgs a{st.qkv[l], st.attn[l], save ? st.lse[l] : nullptr, st.N, st.L, st.H, 1};
+      ProfScope ps(E, s, PC_ATTN_FWD, 2.0 * st.L * st.L * 64.0 * st.N * st.H, (double)T * dtw * 2.0 * 4.0);
+      HIPCHK(E, launch_attn_fwd(E->dt, a, s));
+    }
+    { ProfScope ps(E, s, PC_GLUE, 0, (double)C * dtw * 12.0);
+      HIPCHK(E, launch_copy_rows(st.attn[l], E->tac16, E->eot_rows, C, dtw * 2, 0, s));
+      HIPCHK(E, launch_copy_rows(xin, E->txc32, E->eot_rows, C, dtw * 4, 0, s)); }
+    HIPCHK(E, gemm(E, EPI_RESID32, E->tac16, Bk.o.w, C, dtw, dtw, Bk.o.b, nullptr, E->txc32, E->txm32, nullptr, s));
+    HIPCHK(E, ln_fwd(E, E->dt, E->txm32, nullptr, 1, Bk.ln2, E->thc16, C, dtw, s));
+    HIPCHK(E, gemm(E, EPI_GELU, E->thc16, Bk.fc.w, C, 4 * dtw, dtw, Bk.fc.b, nullptr, nullptr, E->tgc16, save ? E->tuc16 : nullptr, s));
+    HIPCHK(E, gemm(E, EPI_RESID32, E->tgc16, Bk.pr.w, C, dtw, 4 * dtw, Bk.pr.b, nullptr, E->txm32, E->txo32, nullptr, s));
+    HIPCHK(E, ln_fwd(E, DT_F32, E->txo32, nullptr, 1, E->ln_final, E->eot32, C, dtw, s));
+  }
   { ProfScope ps(E, s, PC_HEAD, 2.0 * C * e * dtw, 4.0 * ((double)C * dtw + (double)e * dtw + (double)C * e));
     HIPCHK(E, launch_sgemm_bt(E->eot32, E->tproj_t, feat_out, C, e, dtw, nullptr, s)); }
   return 0;
@@ -648,10 +681,31 @@ int mvlpt_text_bwd(void* h, const float* dfeat, float* dctx, mvlpt_stream_t stre
     HIPCHK(E, launch_sgemm_bt(dfeat, E->tproj, E->deot32, C, dtw, e, st.scale_dev, s)); }
   { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dtw * 4.0);
     HIPCHK(E, launch_zero(st.dx32, T * dtw * 4, s)); }
-  HIPCHK(E, ln_bwd(E, E->deot32, DT_F32, st.x[2 * st.layers], E->eot_rows, 1, E->ln_final, nullptr, st.dx32, nullptr, C, dtw, s));
-  { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dtw * 6.0);
-    HIPCHK(E, launch_cast_f32_to16(E->dt, st.dx32, st.dx16, T * dtw, nullptr, s)); }
-  for (int l = st.layers - 1; l >= 0; --l)
+  if (!E->t_eot_last) return fail(E, MVLPT_ERR_STATE, "text_bwd: the forward did not keep the last block's activations");
+  {
+    // last block on the C compact EOT rows (see mvlpt_text_fwd); the attention backward runs at full width on a dO that
+    // is zero except for the EOT rows, then the QKV^T GEMM and ln_1 as usual
+    const int l = st.layers - 1;
+    const Block& Bk = E->txt.blocks[l];
+    const int Ti = (int)T;
+    HIPCHK(E, ln_bwd(E, E->deot32, DT_F32, E->txo32, nullptr, 1, E->ln_final, nullptr, E->tdxc32, E->tdxc16, C, dtw, s));
+    HIPCHK(E, gemm(E, EPI_GELUBWD, E->tdxc16, Bk.pr.wt, C, 4 * dtw, dtw, nullptr, E->tuc16, nullptr, E->tduc16, nullptr, s));
+    HIPCHK(E, gemm(E, EPI_STORE32, E->tduc16, Bk.fc.wt, C, dtw, 4 * dtw, nullptr, nullptr, nullptr, E->tdhc32, nullptr, s));
+    HIPCHK(E, ln_bwd(E, E->tdhc32, DT_F32, E->txm32, nullptr, 1, Bk.ln2, E->tdxc32, E->tdxc32, E->tdxc16, C, dtw, s));
+    HIPCHK(E, gemm(E, EPI_STORE16, E->tdxc16, Bk.o.wt, C, dtw, dtw, nullptr, nullptr, nullptr, E->tdOc16, nullptr, s));
+    { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dtw * 2.0);
+      HIPCHK(E, launch_zero(st.dO16, T * dtw * 2, s));
+      HIPCHK(E, launch_copy_rows(E->tdOc16, st.dO16, E->eot_rows, C, dtw * 2, 1, s));
+      HIPCHK(E, launch_copy_rows(E->tdxc32, st.dx32, E->eot_rows, C, dtw * 4, 1, s)); }     // residual path (dx32 was zeroed)
+    {
+      AttnBwdArgs a{st.qkv[l], st.attn[l], st.dO16, st.lse[l], st.delta, st.dqkv16, st.N, st.L, st.H, 1};
+      ProfScope ps(E, s, PC_ATTN_BWD, 7.0 * st.L * st.L * 64.0 * st.N * st.H, (double)T * dtw * 2.0 * 8.0);
+      HIPCHK(E, launch_attn_bwd(E->dt, a, s));
+    }
+    HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, Bk.qkv.wt, Ti, dtw, 3 * dtw, nullptr, nullptr, nullptr, st.dh32, nullptr, s));
+    HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, Bk.ln1, st.dx32, st.dx32, st.dx16, Ti, dtw, s));
+  }
+  for (int l = st.layers - 2; l >= 0; --l)
     if (int rc = block_bwd(E, E->txt, st, l, s)) return rc;
   { ProfScope ps(E, s, PC_GLUE, 0, (double)C * E->t_nctx * dtw * 4.0);
     HIPCHK(E, launch_gather_ctx_grad(st.dx32, E->ctx_pos, C, L, dtw, E->t_nctx, E->t_per_class, dctx, st.scale_dev, s)); }

@@ -355,6 +355,27 @@ __global__ void eot_rows_kernel(const int32_t* __restrict__ eot, int32_t* __rest
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) rows[c] = c * L + eot[c];
 }
+// dst[r] = src[idx[r]] (gather) or dst[idx[r]] = src[r] (scatter); rows of row_bytes (a multiple of 16) bytes
+__global__ void copy_rows_kernel(const char* __restrict__ src, char* __restrict__ dst, const int32_t* __restrict__ idx, int rows,
+                                 int row_bytes, int scatter) {
+  const int chunks = row_bytes / 16;
+  const size_t total = (size_t)rows * chunks;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / chunks), c = (int)(i % chunks);
+    const size_t far = (size_t)idx[r] * row_bytes + (size_t)c * 16, near = (size_t)r * row_bytes + (size_t)c * 16;
+    if (scatter) *(f32x4*)(dst + far) = *(const f32x4*)(src + near);
+    else *(f32x4*)(dst + near) = *(const f32x4*)(src + far);
+  }
+}
+hipError_t launch_copy_rows(const void* src, void* dst, const int32_t* idx, int rows, int row_bytes, int scatter, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (row_bytes % 16) return hipErrorInvalidValue;
+  const size_t total = (size_t)rows * (row_bytes / 16);
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(256), 0, s, (const char*)src, (char*)dst, idx, rows, row_bytes, scatter);
+  return hipGetLastError();
+}
+
 hipError_t launch_eot_rows(const int32_t* eot, int32_t* rows, int C, int L, hipStream_t s) {
   hipLaunchKernelGGL(eot_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, s, eot, rows, C, L);
   return hipGetLastError();

@@ -113,6 +113,8 @@ hipError_t launch_assemble_prompts(const float* prefix, const float* suffix, con
                                    const int32_t* layout, const float* pos, float* x, int C, int L, int d, hipStream_t s);
 hipError_t launch_build_ctx_pos(const int32_t* layout, int32_t* ctx_pos, int C, int L, int n_ctx, hipStream_t s);
 hipError_t launch_eot_rows(const int32_t* eot, int32_t* rows, int C, int L, hipStream_t s);
+// dst[r] = src[idx[r]] (scatter = 0) or dst[idx[r]] = src[r] (scatter = 1); row_bytes % 16 == 0
+hipError_t launch_copy_rows(const void* src, void* dst, const int32_t* idx, int rows, int row_bytes, int scatter, hipStream_t s);
 // out[j,:] = inv_scale * sum_b dx[b, row0+j, :]; optionally zero those rows of dx32/dx16 afterwards
 hipError_t launch_reduce_prompt_rows(int dtype, float* dx32, void* dx16, int B, int L, int d, int row0, int n, float* out,
                                      const float* scale_dev, int zero_after, hipStream_t s);
