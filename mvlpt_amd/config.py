@@ -52,7 +52,7 @@ def get_cfg_default() -> CfgNode:
     # configs/trainers/MVLPT/vit_b16.yaml:15-22 + Dassl optimizer defaults
     cfg.OPTIM = CN(NAME="sgd", LR=0.002, MAX_EPOCH=200, MOMENTUM=0.9, WEIGHT_DECAY=5e-4, SGD_DAMPNING=0.0,
                    SGD_NESTEROV=False, LR_SCHEDULER="cosine", WARMUP_EPOCH=1, WARMUP_TYPE="constant",
-                   WARMUP_CONS_LR=1e-5)
+                   WARMUP_CONS_LR=1e-5, WARMUP_MIN_LR=1e-5)
     cfg.TRAIN = CN(PRINT_FREQ=5, CHECKPOINT_FREQ=0)
     cfg.TEST = CN(FINAL_MODEL="last_step", SPLIT="test")
     cfg.TRAINER = CN(NAME="MVLPT", CUT_CONTEXTLEN=False, ACT_CKPT=1)

@@ -25,6 +25,20 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_device(fn):
+    """Run an Engine method with the engine's GPU current: `_stream()` then returns THAT device's current stream and the
+    library's internal hipMalloc / kernel launches land on it (one process per GPU, but rank r's GPU is cuda:r, not 0)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        if torch.cuda.current_device() == self.device.index:
+            return fn(self, *a, **k)
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a CUDA/HIP tensor: mvlpt_amd has no CPU path")
@@ -40,6 +54,8 @@ class Engine:
         if not torch.cuda.is_available():
             raise RuntimeError("mvlpt_amd.Engine needs a HIP device (no CPU fallback)")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.index is None:
+            self.device = torch.device(f"cuda:{torch.cuda.current_device()}")
         self.arch = arch
         self.dt = {"fp16": DT_F16, "bf16": DT_BF16}[compute_dtype]
         self.torch_dtype = _DT2TORCH[self.dt]
@@ -90,6 +106,7 @@ class Engine:
             _lib.check(lib.mvlpt_frozen_ready(self.h), self.h, "frozen_ready")
 
     # ------------------------------------------------------------------ towers
+    @_on_device
     def image_fwd(self, image: torch.Tensor, vpt: Optional[torch.Tensor] = None, vpt_deep: Optional[torch.Tensor] = None,
                   save_for_bwd: bool = False) -> torch.Tensor:
         if image.dtype not in _TORCH2DT:
@@ -111,6 +128,7 @@ class Engine:
         self._img_state = (n_vpt, n_deep, B) if save_for_bwd else None
         return feat
 
+    @_on_device
     def image_bwd(self, dfeat: torch.Tensor) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
         if self._img_state is None:
             raise RuntimeError("image_bwd without image_fwd(save_for_bwd=True)")
@@ -122,6 +140,7 @@ class Engine:
         _lib.check(lib.mvlpt_image_bwd(self.h, _ptr(dfeat), _ptr(dvpt), _ptr(ddeep), _stream()), self.h, "image_bwd")
         return dvpt, ddeep
 
+    @_on_device
     def text_fwd(self, prefix: torch.Tensor, suffix: torch.Tensor, ctx: Optional[torch.Tensor], layout: torch.Tensor,
                  eot: torch.Tensor, save_for_bwd: bool = False) -> torch.Tensor:
         prefix = _req(prefix, torch.float32, "token_prefix")
@@ -140,6 +159,7 @@ class Engine:
         self._txt_state = (tuple(ctx.shape) if ctx is not None else None, layout, eot) if save_for_bwd else None
         return feat
 
+    @_on_device
     def text_bwd(self, dfeat: torch.Tensor) -> torch.Tensor:
         if self._txt_state is None or self._txt_state[0] is None:
             raise RuntimeError("text_bwd without text_fwd(save_for_bwd=True) with context tokens")
@@ -149,6 +169,7 @@ class Engine:
         return dctx
 
     # ------------------------------------------------------------------ head
+    @_on_device
     def logits_fwd(self, img_feat, txt_feat, logit_scale_exp: float, task_lo=None, task_hi=None) -> torch.Tensor:
         img_feat = _req(img_feat, torch.float32, "img_feat")
         txt_feat = _req(txt_feat, torch.float32, "txt_feat")
@@ -162,6 +183,7 @@ class Engine:
         self._head_state = (task_lo, task_hi, B, Cn)   # keep the mask tensors alive until logits_bwd
         return logits
 
+    @_on_device
     def logits_bwd(self, dlogits, need_img: bool = True, need_txt: bool = True):
         if self._head_state is None:
             raise RuntimeError("logits_bwd without logits_fwd")
@@ -173,6 +195,7 @@ class Engine:
         _lib.check(lib.mvlpt_logits_bwd(self.h, _ptr(dlogits), _ptr(dimg), _ptr(dtxt), _stream()), self.h, "logits_bwd")
         return dimg, dtxt
 
+    @_on_device
     def cross_entropy(self, logits, label, need_grad: bool = True):
         """Returns (loss[1], dlogits or None, ncorrect[1]) — device tensors, no host sync."""
         logits = _req(logits, torch.float32, "logits")
@@ -195,6 +218,7 @@ class Engine:
         return loss, dl, nc
 
     # ------------------------------------------------------------------ input pipeline
+    @_on_device
     def preprocess(self, src: torch.Tensor, descs, out_size, mean, std, out_dtype=torch.float32, want_u8: bool = False):
         """src: uint8 device tensor holding the packed decoded HWC images; descs: `_lib.MvlptImageDesc` ctypes array.
         Returns [B,3,h,w] normalised images (and the resized 8-bit images [B,h,w,3] when `want_u8`)."""
@@ -212,12 +236,15 @@ class Engine:
         return (out, u8) if want_u8 else out
 
     # ------------------------------------------------------------------ profiling
+    @_on_device
     def profile_begin(self, all_kernels: bool = False):
         _lib.check(lib.mvlpt_profile_begin(self.h, int(all_kernels)), self.h, "profile_begin")
 
+    @_on_device
     def profile_pause(self, paused: bool):
         _lib.check(lib.mvlpt_profile_pause(self.h, int(paused)), self.h, "profile_pause")
 
+    @_on_device
     def profile_end(self) -> Dict[str, dict]:
         arr = (_lib.MvlptKernelStat * 16)()
         n = lib.mvlpt_profile_end(self.h, arr, 16)

@@ -297,36 +297,37 @@ class MultitaskVLPromptLearner(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ class sharding
-def _gather_class_shards(loc: torch.Tensor, cmax: int, world: int, n_cls: int) -> torch.Tensor:
+def class_shard_bounds(n_cls: int, world: int):
+    """Balanced contiguous split of the classes over the ranks: the first n_cls % world ranks own one class more."""
+    base, rem = divmod(n_cls, world)
+    return [(r * base + min(r, rem), (r + 1) * base + min(r + 1, rem)) for r in range(world)]
+
+
+def _gather_class_shards(loc: torch.Tensor, bounds, cmax: int) -> torch.Tensor:
     """all-gather of per-rank text features [c_r, e] (c_r <= cmax) -> [n_cls, e] (RCCL over xGMI: <= 4.5 MB)."""
     import torch.distributed as dist
-    e = loc.shape[1]
+    e, world = loc.shape[1], len(bounds)
     pad = torch.zeros(cmax, e, device=loc.device, dtype=loc.dtype)
     pad[:loc.shape[0]] = loc
     out = torch.empty(world * cmax, e, device=loc.device, dtype=loc.dtype)
     dist.all_gather_into_tensor(out, pad)
-    rows = []
-    for r in range(world):
-        c_r = max(0, min(cmax, n_cls - r * cmax))
-        rows.append(out[r * cmax:r * cmax + c_r])
-    return torch.cat(rows, dim=0)
+    return torch.cat([out[r * cmax:r * cmax + (hi - lo)] for r, (lo, hi) in enumerate(bounds)], dim=0)
 
 
-def _scatter_class_grads(dtxt: torch.Tensor, lo: int, hi: int, cmax: int, world: int) -> torch.Tensor:
+def _scatter_class_grads(dtxt: torch.Tensor, bounds, cmax: int, rank: int) -> torch.Tensor:
     """reduce-scatter (sum) of d txt [n_cls, e] back to the class owners -> [hi-lo, e]."""
     import torch.distributed as dist
-    n_cls, e = dtxt.shape
+    e, world = dtxt.shape[1], len(bounds)
     buf = torch.zeros(world * cmax, e, device=dtxt.device, dtype=dtxt.dtype)
-    for r in range(world):
-        c_r = max(0, min(cmax, n_cls - r * cmax))
-        buf[r * cmax:r * cmax + c_r] = dtxt[r * cmax:r * cmax + c_r]
+    for r, (lo, hi) in enumerate(bounds):
+        buf[r * cmax:r * cmax + (hi - lo)] = dtxt[lo:hi]
     if dist.get_backend() == "gloo":          # CPU tests: gloo has no reduce_scatter
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        rank = dist.get_rank()
         own = buf[rank * cmax:(rank + 1) * cmax]
     else:
         own = torch.empty(cmax, e, device=dtxt.device, dtype=dtxt.dtype)
         dist.reduce_scatter_tensor(own, buf, op=dist.ReduceOp.SUM)
+    lo, hi = bounds[rank]
     return own[:hi - lo].contiguous()
 
 
@@ -374,6 +375,9 @@ class _PromptedClipFn(torch.autograd.Function):
                 pre[3].record_stream(torch.cuda.current_stream())
                 return pre[3]
         else:
+            if pre is not None:
+                # a prefetch for ANOTHER tensor is (or was) writing the image-tower workspace on its own stream
+                torch.cuda.current_stream().wait_event(pre[4])
             image_fwd = eng.image_fwd
         shard = model._class_shard if (run_text and coop_emb is not None) else None
         side = model._side_stream if (run_text and model.overlap_towers and shard is None) else None
@@ -381,11 +385,12 @@ class _PromptedClipFn(torch.autograd.Function):
             # Class-sharded text tower (collective 2): this rank encodes classes [lo, hi) only, the
             # features are all-gathered; the backward reduce-scatters d(txt) back to the owners.
             img = image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
-            lo, hi, cmax, world = shard
+            rank, bounds, cmax = shard
+            lo, hi = bounds[rank]
             ctx_loc = coop_emb if coop_emb.dim() == 2 else coop_emb[lo:hi]
             loc = eng.text_fwd(pl.token_prefix[lo:hi], suffix[lo:hi], ctx_loc, layout[lo:hi], pl.eot[lo:hi],
                                save_for_bwd=need_txt)
-            txt = _gather_class_shards(loc, cmax, world, pl.n_cls)
+            txt = _gather_class_shards(loc, bounds, cmax)
         elif side is not None:
             # The two towers are independent until the logits: the text tower (few, small launches that cannot
             # fill 256 CUs) runs on a second HIP stream underneath the image tower's large GEMMs.
@@ -409,6 +414,11 @@ class _PromptedClipFn(torch.autograd.Function):
         if coop_emb is not None:
             model._const_text_features = None    # only the no-context case may persist across training steps
         logits = eng.logits_fwd(img, txt, model.logit_scale_exp, task_lo, task_hi)
+        # the engine keeps ONE set of saved activations per tower: stamp this forward so that a backward that arrives
+        # after another forward has overwritten them (gradient accumulation, test() between forward and backward) is
+        # refused instead of silently using the wrong activations
+        model._fwd_generation += 1
+        fctx.generation = model._fwd_generation
         fctx.model, fctx.need_img, fctx.need_txt = model, need_img, need_txt
         fctx.shard, fctx.ctx_shape = shard, (None if coop_emb is None else coop_emb.shape)
         fctx.has_deep = vpt_deep_emb is not None
@@ -418,13 +428,17 @@ class _PromptedClipFn(torch.autograd.Function):
     @staticmethod
     def backward(fctx, dlogits):
         eng = fctx.model.engine
+        if fctx.generation != fctx.model._fwd_generation:
+            raise RuntimeError("backward of a stale forward: the engine holds the saved activations of the most recent "
+                               "CustomCLIP.forward only (call backward before the next forward)")
         dimg, dtxt = eng.logits_bwd(dlogits.contiguous(), fctx.need_img, fctx.need_txt)
         dctx = dvpt = ddeep = None
         if fctx.need_txt and fctx.shard is not None:
-            lo, hi, cmax, world = fctx.shard
+            rank, bounds, cmax = fctx.shard
+            lo, hi = bounds[rank]
             # sum over ranks of d(local loss)/d(txt) for the classes this rank owns; the trainer's gradient
             # all-reduce (mean over ranks) then yields d(global mean loss)/d(ctx) summed over all class shards
-            own = _scatter_class_grads(dtxt, lo, hi, cmax, world)
+            own = _scatter_class_grads(dtxt, bounds, cmax, rank)
             dloc = eng.text_bwd(own)
             if len(fctx.ctx_shape) == 3:                      # class-specific contexts: only the owned rows are non-zero
                 dctx = torch.zeros(fctx.ctx_shape, device=dloc.device, dtype=dloc.dtype)
@@ -476,6 +490,7 @@ class CustomCLIP(nn.Module):
         self.trim_text_to_eot = False
         self._prefetch_stream = None
         self._prefetched = None
+        self._fwd_generation = 0
         self._side_stream = torch.cuda.Stream(device=clip_model.device) if torch.cuda.is_available() else None
         self.multi_task_label_pertask = cfg.DATASET.MULTITASK_LABEL_PERTASK
         if self.multi_task_label_pertask:
@@ -496,11 +511,10 @@ class CustomCLIP(nn.Module):
             self._class_shard = None
             return
         C = self.prompt_learner.n_cls
-        cmax = (C + world - 1) // world
-        lo, hi = min(C, rank * cmax), min(C, (rank + 1) * cmax)
-        if hi <= lo:
-            raise ValueError("more ranks than classes: class sharding needs at least one class per rank")
-        self._class_shard = (lo, hi, cmax, world)
+        if world > C:
+            raise ValueError(f"class sharding needs at least one class per rank ({C} classes, {world} ranks)")
+        bounds = class_shard_bounds(C, world)
+        self._class_shard = (rank, bounds, max(hi - lo for lo, hi in bounds))
 
     def prefetch_image_features(self, image) -> bool:
         """Software pipelining across steps: with no visual prompts the image tower is a pure function of the image

@@ -41,23 +41,55 @@ def build_optimizer(model: torch.nn.Module, optim_cfg) -> torch.optim.Optimizer:
     raise ValueError(f"unsupported optimizer {optim_cfg.NAME}")
 
 
+def load_pretrained_weights(model: torch.nn.Module, weight_path: str) -> None:
+    """Dassl `load_pretrained_weights` (recalled): keys that are missing in the model or whose shape
+    differs are dropped (a checkpoint trained with another class count still warm-starts the prompts); the class
+    dependent buffers token_prefix / token_suffix always come from THIS model's tokenisation."""
+    ck = torch.load(weight_path, map_location="cpu")
+    sd = ck.get("state_dict", ck)
+    own = model.state_dict()
+    keep, dropped = {}, []
+    for k, v in sd.items():
+        k = k[7:] if k.startswith("module.") else k
+        if k in ("token_prefix", "token_suffix") or k not in own or own[k].shape != v.shape:
+            dropped.append(k)
+            continue
+        keep[k] = v
+    if not keep:
+        raise RuntimeError(f'The pretrained weights "{weight_path}" cannot be loaded, check the key names')
+    own.update(keep)
+    model.load_state_dict(own)
+    if dropped:
+        print(f"load_pretrained_weights: layers discarded due to unmatched keys or size: {dropped}")
+
+
 class _ConstantWarmupCosine:
     """CosineAnnealingLR(T_max = MAX_EPOCH) behind a constant warm-up (WARMUP_EPOCH at WARMUP_CONS_LR);
     stepped once per epoch (trainers/mvlpt.py:948-949)."""
 
     def __init__(self, optim, optim_cfg):
+        if optim_cfg.WARMUP_EPOCH > 0 and optim_cfg.WARMUP_TYPE not in ("constant", "linear"):
+            raise ValueError(f"unsupported OPTIM.WARMUP_TYPE {optim_cfg.WARMUP_TYPE!r} (constant | linear)")
+        if optim_cfg.LR_SCHEDULER != "cosine":      # every reference config uses cosine (configs/trainers/MVLPT/*.yaml)
+            raise ValueError(f"unsupported OPTIM.LR_SCHEDULER {optim_cfg.LR_SCHEDULER!r} (only cosine)")
         self.optim, self.cfg = optim, optim_cfg
         self.base_lrs = [g["lr"] for g in optim.param_groups]
         self.last_epoch = 0
         self._apply()
 
     def _lr(self, base):
+        # Dassl's warm-up wrappers only start stepping their successor once the warm-up is over, so the successor
+        # (CosineAnnealingLR, T_max = MAX_EPOCH) sees epoch e - WARMUP_EPOCH: the first epoch after the warm-up runs
+        # at the full base LR (recalled from Dassl's _BaseWarmupScheduler.step; SURVEY Appendix B).
         c = self.cfg
-        if self.last_epoch < c.WARMUP_EPOCH and c.WARMUP_TYPE == "constant":
-            return c.WARMUP_CONS_LR
-        if c.LR_SCHEDULER == "cosine":
-            return 0.5 * base * (1 + math.cos(math.pi * self.last_epoch / c.MAX_EPOCH))
-        return base
+        W = c.WARMUP_EPOCH
+        if self.last_epoch < W:
+            if c.WARMUP_TYPE == "constant":
+                return c.WARMUP_CONS_LR
+            if self.last_epoch == 0:                      # LinearWarmupScheduler
+                return c.WARMUP_MIN_LR
+            return base * self.last_epoch / W
+        return 0.5 * base * (1 + math.cos(math.pi * (self.last_epoch - W) / c.MAX_EPOCH))
 
     def _apply(self):
         for g, b in zip(self.optim.param_groups, self.base_lrs):
@@ -87,6 +119,9 @@ class TrainerX:
         self.cfg = cfg
         self.rank, self.world_size, self.local_rank = dist_utils.rank_info()
         self.device = torch.device(f"cuda:{self.local_rank}") if torch.cuda.is_available() else torch.device("cpu")
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)      # the engine's workspaces and streams live on THIS rank's GPU
+        dist_utils.init_process_group()             # no-op for one process or when the launcher already did it
         self.start_epoch = self.epoch = 0
         self.max_epoch = cfg.OPTIM.MAX_EPOCH
         self.output_dir = cfg.OUTPUT_DIR
@@ -252,6 +287,12 @@ class MVLPT(TrainerX):
         super().__init__(cfg)
 
     def check_cfg(self, cfg):
+        """:835-836 accepts fp16 | fp32 | amp.  Mapping onto the MI355X engine ("Precision modes"):
+          fp16 : fp16 MFMA operands, fp32 accumulation / LayerNorm / softmax / residual stream; towers that carry a
+                 gradient run with split (hi + lo) operands so that prompt gradients match the fp32 CPU path to 1e-3
+          amp  : same engine mode (fp32 master prompts + 16-bit compute + internal gradient scaling IS this engine's
+                 fp16 mode; there is no GradScaler object, self.scaler stays None)
+          fp32 : every tower in the split-operand mode, forward-only towers included (~22-bit products)."""
         assert cfg.TRAINER.MVLPT.PREC in ["fp16", "fp32", "amp"]        # :835-836
 
     def build_data_loader(self):
@@ -278,8 +319,7 @@ class MVLPT(TrainerX):
             if "prompt_learner" not in name:
                 param.requires_grad_(False)
         if cfg.MODEL.INIT_WEIGHTS:
-            ck = torch.load(cfg.MODEL.INIT_WEIGHTS, map_location="cpu")
-            self.model.prompt_learner.load_state_dict(ck.get("state_dict", ck), strict=False)
+            load_pretrained_weights(self.model.prompt_learner, cfg.MODEL.INIT_WEIGHTS)    # :864-865
         self.model.to(self.device)
         if self.world_size > 1:
             dist_utils.broadcast_parameters(self.model.prompt_learner)   # identical prompts on every rank

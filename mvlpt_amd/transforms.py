@@ -75,7 +75,10 @@ class DeviceTransform:
         self.engine, self.size, self.train, self.center_crop = engine, int(size), train, center_crop
         self.mean, self.std, self.scale, self.ratio, self.flip_p = tuple(mean), tuple(std), scale, ratio, flip_p
         self.out_dtype, self.generator = out_dtype, generator
-        self._pinned: Optional[torch.Tensor] = None
+        # ring of pinned staging buffers, each guarded by the event of its last H2D copy: the train step does not
+        # synchronise per step, so the copy of batch i may still be queued when batch i+1 is packed
+        self._ring: List[list] = [[None, None] for _ in range(3)]      # [pinned tensor, torch.cuda.Event]
+        self._slot = -1
 
     def describe(self, shapes: Sequence[Tuple[int, int]]):
         """Descriptors (ctypes array) for images of the given (height, width); draws the random parameters."""
@@ -105,22 +108,31 @@ class DeviceTransform:
     def pack(self, images: Sequence) -> Tuple[torch.Tensor, int]:
         """Copies the decoded images back to back into a (re-used) pinned host buffer."""
         total = sum(int(np.prod(im.shape)) for im in images)
-        if self._pinned is None or self._pinned.numel() < total:
-            self._pinned = torch.empty(max(total, 1), dtype=torch.uint8)
+        self._slot = (self._slot + 1) % len(self._ring)
+        ent = self._ring[self._slot]
+        if ent[1] is not None:
+            ent[1].synchronize()                      # the upload that last read this buffer has completed
+        if ent[0] is None or ent[0].numel() < total:
+            ent[0] = torch.empty(max(total, 1), dtype=torch.uint8)
             if torch.cuda.is_available():
-                self._pinned = self._pinned.pin_memory()
+                ent[0] = ent[0].pin_memory()
+        pinned = ent[0]
         off = 0
         for im in images:
             a = im if torch.is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im))
             if a.dtype != torch.uint8 or a.dim() != 3 or a.shape[2] != 3:
                 raise ValueError("images must be uint8 HWC with 3 channels")
             n = a.numel()
-            self._pinned[off:off + n].copy_(a.reshape(-1))
+            pinned[off:off + n].copy_(a.reshape(-1))
             off += n
-        return self._pinned, total
+        return pinned, total
 
     def __call__(self, images: Sequence, want_u8: bool = False):
         descs, total = self.describe([(int(im.shape[0]), int(im.shape[1])) for im in images])
         host, n = self.pack(images)
         src = host[:n].to(self.engine.device if hasattr(self.engine, "device") else "cuda", non_blocking=True)
+        if src.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(src.device))
+            self._ring[self._slot][1] = ev
         return self.engine.preprocess(src, descs, self.size, self.mean, self.std, self.out_dtype, want_u8)

@@ -58,5 +58,83 @@ def test_lr_schedule_constant_warmup_then_cosine():
         lrs.append(opt.param_groups[0]["lr"])
         sch.step()
     assert lrs[0] == 1e-5                                          # WARMUP_CONS_LR for WARMUP_EPOCH=1
-    assert abs(lrs[1] - 0.5 * 0.002 * (1 + np.cos(np.pi * 1 / 10))) < 1e-12
-    assert all(a > b for a, b in zip(lrs[1:], lrs[2:]))
+    # Dassl's ConstantWarmupScheduler steps its successor only after the warm-up: torch's own CosineAnnealingLR,
+    # started one epoch late, is the comparator (first post-warm-up epoch at the full base LR)
+    ref_opt = torch.optim.SGD(torch.nn.Linear(2, 2).parameters(), lr=0.002)
+    ref = torch.optim.lr_scheduler.CosineAnnealingLR(ref_opt, T_max=10)
+    for e in range(1, 10):
+        assert abs(lrs[e] - ref_opt.param_groups[0]["lr"]) < 1e-12, e
+        ref_opt.step()
+        ref.step()
+    assert lrs[1] == 0.002 and all(a > b for a, b in zip(lrs[1:], lrs[2:]))
+
+
+def test_lr_schedule_linear_warmup_and_rejections():
+    from mvlpt_amd.config import get_cfg_default
+    from mvlpt_amd.trainer import build_lr_scheduler, build_optimizer
+    cfg = get_cfg_default()
+    cfg.OPTIM.MAX_EPOCH, cfg.OPTIM.WARMUP_EPOCH, cfg.OPTIM.WARMUP_TYPE = 10, 3, "linear"
+    opt = build_optimizer(torch.nn.Linear(2, 2), cfg.OPTIM)
+    sch = build_lr_scheduler(opt, cfg.OPTIM)
+    lrs = []
+    for _ in range(5):
+        lrs.append(opt.param_groups[0]["lr"])
+        sch.step()
+    assert lrs[0] == 1e-5 and abs(lrs[1] - 0.002 / 3) < 1e-12 and abs(lrs[2] - 0.004 / 3) < 1e-12 and lrs[3] == 0.002
+    cfg.OPTIM.WARMUP_TYPE = "exponential"
+    with pytest.raises(ValueError):
+        build_lr_scheduler(opt, cfg.OPTIM)
+    cfg.OPTIM.WARMUP_TYPE, cfg.OPTIM.LR_SCHEDULER = "constant", "multi_step"
+    with pytest.raises(ValueError):
+        build_lr_scheduler(opt, cfg.OPTIM)
+
+
+def test_class_shard_bounds_balanced():
+    from mvlpt_amd.model import class_shard_bounds
+    assert class_shard_bounds(9, 4) == [(0, 3), (3, 5), (5, 7), (7, 9)]          # ceil-split would leave rank 3 empty
+    assert class_shard_bounds(2191, 8)[-1][1] == 2191
+    for C, W in [(5, 2), (100, 8), (1151, 8), (8, 8)]:
+        b = class_shard_bounds(C, W)
+        assert b[0][0] == 0 and b[-1][1] == C and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1 and min(h - l for l, h in b) >= 1
+
+
+def _tiny_oracle_model(n_ctx=4, names=("dog", "grand piano", "sea horse")):
+    from mvlpt_amd.config import get_cfg_default
+    from mvlpt_amd.model import CustomCLIP
+    from mvlpt_amd.weights import ARCHS, make_state_dict
+    from tests.fake_engine import OracleFrozenCLIP
+    arch = ARCHS["tiny"]
+    cfg = get_cfg_default()
+    cfg.INPUT.SIZE = (32, 32)
+    cfg.TRAINER.MVLPT.COOP.N_CTX = n_ctx
+    torch.manual_seed(3)
+    return CustomCLIP(cfg, list(names), OracleFrozenCLIP(make_state_dict(arch, seed=5), arch)), cfg
+
+
+def test_stale_backward_is_refused():
+    """the engine keeps one set of saved activations: backward of an older forward must raise, not use the wrong ones"""
+    model, _ = _tiny_oracle_model()
+    img = torch.randn(2, 3, 32, 32)
+    loss_a = model.cross_entropy(model(img), torch.tensor([0, 1]))
+    loss_b = model.cross_entropy(model(img + 1.0), torch.tensor([1, 2]))
+    with pytest.raises(RuntimeError, match="stale forward"):
+        loss_a.backward()
+    loss_b.backward()
+    assert model.prompt_learner.ctx.grad is not None
+
+
+def test_init_weights_drop_class_buffers_and_mismatched_shapes(tmp_path):
+    """MODEL.INIT_WEIGHTS from a checkpoint with ANOTHER class count (trainers/mvlpt.py:864-865 + Dassl
+    load_pretrained_weights): ctx is taken, token_prefix / token_suffix are not."""
+    from mvlpt_amd.trainer import load_pretrained_weights
+    src, _ = _tiny_oracle_model(names=("a", "b", "c", "d", "e"))
+    dst, _ = _tiny_oracle_model()
+    sd = {k: v.clone() for k, v in src.prompt_learner.state_dict().items()}
+    sd["ctx"] += 1.0
+    path = tmp_path / "init.pth.tar"
+    torch.save({"state_dict": sd, "epoch": 3}, path)
+    before = dst.prompt_learner.token_suffix.clone()
+    load_pretrained_weights(dst.prompt_learner, str(path))
+    assert torch.equal(dst.prompt_learner.ctx.data, sd["ctx"])
+    assert torch.equal(dst.prompt_learner.token_suffix, before) and dst.prompt_learner.token_suffix.shape[0] == 3
