@@ -38,7 +38,19 @@ typedef struct MvlptArch {
   int compute_dtype; /* MVLPT_DT_F16 (reference default PREC, train.py:131) or MVLPT_DT_BF16 */
 } MvlptArch;
 
+/* Precision mode of the towers (reference knob: TRAINER.MVLPT.PREC, trainers/mvlpt.py:835-836, 848-850).
+ * All modes: 16-bit MFMA operands, fp32 accumulation, fp32 residual stream / LayerNorm / softmax / cross-entropy.
+ *   MVLPT_PREC_FAST       single 16-bit operands everywhere (prompt gradients within ~4e-3 of the fp32 CPU path)
+ *   MVLPT_PREC_SPLIT_GRAD default: a tower whose forward is saved for a backward runs with SPLIT operands — every GEMM A
+ *                         operand is a hi+lo pair of 16-bit values (~22 bits; the frozen weights are exactly 16-bit), and the
+ *                         attention core runs in fp32 — so prompt gradients match the fp32 CPU path to 1e-3; forward-only
+ *                         towers (e.g. the image tower under CoOp, inference) stay in the fast mode
+ *   MVLPT_PREC_SPLIT_ALL  split operands in every tower (PREC = "fp32") */
+enum { MVLPT_PREC_FAST = 0, MVLPT_PREC_SPLIT_GRAD = 1, MVLPT_PREC_SPLIT_ALL = 2 };
+
 int mvlpt_create(const MvlptArch* arch, void** handle);
+/* switch the precision mode (takes effect at the next tower forward) */
+int mvlpt_set_precision(void* handle, int mode);
 int mvlpt_destroy(void* handle);
 const char* mvlpt_last_error(void* handle); /* handle may be NULL for create() failures */
 const char* mvlpt_version(void);
@@ -95,6 +107,21 @@ int mvlpt_cross_entropy(void* handle, const float* logits, const void* labels, i
  * 2 fp32 out = acc+bias+resid32, 3 out16 = acc*QuickGELU'(aux16), 4 fp32 store).  K % 64 == 0, N % 128 == 0. */
 int mvlpt_op_gemm(int dtype, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
                   const float* resid, void* out, void* out2, mvlpt_stream_t stream);
+/* same with a split-precision A operand: A is [M, 2K] = [A_hi | A_lo] (16-bit pair), C = (A_hi + A_lo) * Bt^T; additional
+ * epilogues 5 (out [M,2N] = hi|lo pair of QuickGELU(acc+bias), out2 = pre-activation) and 6 (pair of acc*QuickGELU'(aux)) */
+int mvlpt_op_gemm_split(int dtype, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
+                        const float* resid, void* out, void* out2, mvlpt_stream_t stream);
+/* LayerNorm with the 16-bit output written as a hi|lo pair [rows, 2d] */
+int mvlpt_op_layernorm_fwd_split(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
+                                 mvlpt_stream_t stream);
+int mvlpt_op_layernorm_bwd_split(int dtype, const void* dy, const float* x, const float* gamma, const float* resid, float* out32,
+                                 void* out16, int rows, int d, mvlpt_stream_t stream);
+/* fp32 attention core of the split-precision mode: qkv [N*L,3*H*64] fp32 -> out [N*L, 2*H*64] 16-bit hi|lo pair, lse;
+ * backward: dout [N*L,H*64] fp32 -> dqkv [N*L, 6*H*64] 16-bit hi|lo pair (delta: [N*H*L] scratch) */
+int mvlpt_op_attention32_fwd(int dtype, const float* qkv, void* out, float* lse, int N, int L, int H, int causal, int q_rows,
+                             mvlpt_stream_t stream);
+int mvlpt_op_attention32_bwd(int dtype, const float* qkv, const void* out, const float* dout, const float* lse, float* delta,
+                             void* dqkv, int N, int L, int H, int causal, mvlpt_stream_t stream);
 int mvlpt_op_layernorm_fwd(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
                            mvlpt_stream_t stream);
 int mvlpt_op_layernorm_bwd(int dtype, const void* dy, const float* x, const float* gamma, const float* resid, float* out32,
@@ -139,6 +166,7 @@ typedef struct MvlptKernelStat {
   double bytes; /* algorithmic HBM bytes summed over launches */
   double busy_ms; /* length of the UNION of the launch intervals: equals `ms` when launches never overlap; smaller
                      when the same kernel runs concurrently on two streams (image and text tower) */
+  double flops_executed; /* FLOPs the launches actually issued: 2x `flops` for GEMMs with split-precision operands */
 } MvlptKernelStat;
 /* all_kernels == 0: only the dominant kernel (gemm_bt) is timed, through its own dispatch timestamps (no marker
  * packets on the stream); != 0: every kernel class is bracketed by marker events (adds ~1.5 us per event). */

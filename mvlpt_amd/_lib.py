@@ -18,7 +18,8 @@ LIB_PATH = os.environ.get("MVLPT_HIP_LIB") or os.path.join(_HERE, "libmvlpt_hip.
 
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 LABEL_INT64, LABEL_PROB_F32 = 0, 1
-EPI_STORE16, EPI_GELU, EPI_RESID32, EPI_GELUBWD, EPI_STORE32 = 0, 1, 2, 3, 4
+EPI_STORE16, EPI_GELU, EPI_RESID32, EPI_GELUBWD, EPI_STORE32, EPI_GELU_SPLIT, EPI_GELUBWD_SPLIT = 0, 1, 2, 3, 4, 5, 6
+PREC_FAST, PREC_SPLIT_GRAD, PREC_SPLIT_ALL = 0, 1, 2
 
 
 class MvlptArch(C.Structure):
@@ -29,7 +30,7 @@ class MvlptArch(C.Structure):
 
 class MvlptKernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("ms", C.c_double),
-                ("flops", C.c_double), ("bytes", C.c_double), ("busy_ms", C.c_double)]
+                ("flops", C.c_double), ("bytes", C.c_double), ("busy_ms", C.c_double), ("flops_executed", C.c_double)]
 
 
 class MvlptImageDesc(C.Structure):
@@ -44,6 +45,7 @@ _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "mvlpt_create": (_i, [C.POINTER(MvlptArch), C.POINTER(_vp)]),
     "mvlpt_destroy": (_i, [_vp]),
+    "mvlpt_set_precision": (_i, [_vp, _i]),
     "mvlpt_last_error": (C.c_char_p, [_vp]),
     "mvlpt_version": (C.c_char_p, []),
     "mvlpt_load_frozen": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i, _vp]),
@@ -56,6 +58,11 @@ SIGNATURES = {
     "mvlpt_logits_bwd": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mvlpt_cross_entropy": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mvlpt_op_gemm": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvlpt_op_gemm_split": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvlpt_op_layernorm_fwd_split": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mvlpt_op_layernorm_bwd_split": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mvlpt_op_attention32_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvlpt_op_attention32_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvlpt_op_layernorm_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mvlpt_op_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mvlpt_op_attention_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -58,6 +58,7 @@ struct TowerW { int width = 0, layers = 0, heads = 0; std::vector<Block> blocks;
 
 struct TowerState {
   bool valid = false, saved = false, causal = false;
+  bool exact = false;                    // split-precision operands + fp32 attention (see DESIGN.md "Precision modes")
   int N = 0, L = 0, d = 0, H = 0, layers = 0;
   std::vector<float*> x;                 // 2*layers+1 entries (all equal when !saved)
   std::vector<void*> qkv, attn, u;       // per layer (all equal when !saved)
@@ -71,11 +72,12 @@ struct TowerState {
 enum ProfClass { PC_GEMM = 0, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD, PC_GLUE, PC_HEAD, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm_bt", "attention_fwd", "attention_bwd", "layernorm_fwd", "layernorm_bwd",
                                            "glue", "head_logits_ce"};
-struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
+struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes, flops_exec; };
 
 struct Engine {
   MvlptArch arch{};
   int dt = DT_F16;
+  int prec_mode = MVLPT_PREC_SPLIT_GRAD;
   std::string err;
   TowerW vis, txt;
   // vision extras
@@ -123,7 +125,7 @@ struct ProfScope {
     }
     hipEvent_t a = E->ev_pool[E->ev_used++]; b = E->ev_pool[E->ev_used++];
     (void)hipEventRecord(a, s);
-    E->prof.push_back(ProfRec{cls, a, b, flops, bytes});
+    E->prof.push_back(ProfRec{cls, a, b, flops, bytes, flops});
     on = true;
   }
   ~ProfScope() { if (on) (void)hipEventRecord(b, s); }
@@ -131,10 +133,12 @@ struct ProfScope {
 
 // ------------------------------------------------------------------------------------------------ kernel wrappers
 hipError_t gemm(Engine* E, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
-                const float* resid, void* out, void* out2, hipStream_t s, int dtype = -1) {
+                const float* resid, void* out, void* out2, hipStream_t s, int dtype = -1, int a_split = 0) {
   GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
+  g.a_split = a_split;
   const int dt = dtype >= 0 ? dtype : E->dt;
-  const double ob = (epi == EPI_RESID32) ? 8.0 : (epi == EPI_STORE32 ? 4.0 : (epi == EPI_GELUBWD ? 4.0 : 2.0));
+  const double ob = (epi == EPI_RESID32) ? 8.0 : (epi == EPI_STORE32 ? 4.0 : ((epi == EPI_GELUBWD || epi == EPI_GELU_SPLIT) ? 4.0 :
+                    (epi == EPI_GELUBWD_SPLIT ? 6.0 : 2.0)));
   // the dominant kernel is timed by its own dispatch (start/stop timestamps of the AQL packet): no marker packets
   hipEvent_t ea = nullptr, eb = nullptr;
   if (E && E->prof_on) {
@@ -142,70 +146,119 @@ hipError_t gemm(Engine* E, int epi, const void* A, const void* Bt, int M, int N,
       for (int i = 0; i < 512; ++i) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) break; E->ev_pool.push_back(ev); }
     if (E->ev_used + 2 <= E->ev_pool.size()) {
       ea = E->ev_pool[E->ev_used++]; eb = E->ev_pool[E->ev_used++];
+      // flops = ALGORITHMIC (what the reference's fp32 GEMM does: 2MNK); the split-precision mode executes twice that
       E->prof.push_back(ProfRec{PC_GEMM, ea, eb, 2.0 * M * N * K,
-                                2.0 * ((double)M * K + (double)N * K) + ob * M * N + (out2 ? 2.0 * M * N : 0)});
+                                2.0 * ((double)M * K * (a_split ? 2 : 1) + (double)N * K) + ob * M * N + (out2 ? 2.0 * M * N : 0),
+                                2.0 * M * N * K * (a_split ? 2 : 1)});
     }
   }
   return launch_gemm(dt, epi, g, s, ea, eb);
 }
 hipError_t ln_fwd(Engine* E, int out_dt, const float* x, const int32_t* idx, int row_mul, const LNp& p, void* y, int rows, int d,
-                  hipStream_t s) {
+                  hipStream_t s, int split = 0) {
   LnFwdArgs a{x, idx, row_mul, p.g, p.b, y, rows, d};
+  a.split = (split && out_dt != DT_F32) ? 1 : 0;
   ProfScope ps(E, s, PC_LN_FWD, 8.0 * rows * d, (double)rows * d * (4.0 + (out_dt == DT_F32 ? 4.0 : 2.0)));
   return launch_ln_fwd(out_dt, a, s);
 }
 hipError_t ln_bwd(Engine* E, const void* dy, int dy_dtype, const float* x, const int32_t* idx, int row_mul, const LNp& p,
-                  const float* resid, float* out32, void* out16, int rows, int d, hipStream_t s, int dtype = -1) {
+                  const float* resid, float* out32, void* out16, int rows, int d, hipStream_t s, int dtype = -1, int split = 0) {
   LnBwdArgs a{dy, dy_dtype, x, idx, row_mul, p.g, resid, out32, out16, rows, d};
+  a.split = split;
   ProfScope ps(E, s, PC_LN_BWD, 14.0 * rows * d, (double)rows * d * ((dy_dtype == DT_F32 ? 4.0 : 2.0) + 4.0 + (resid ? 4.0 : 0.0) + 4.0 + (out16 ? 2.0 : 0.0)));
   return launch_ln_bwd(dtype >= 0 ? dtype : E->dt, a, s);
 }
 
 // ------------------------------------------------------------------------------------------------ tower workspace
-size_t tower_bytes(const TowerW& W, int N, int L, bool save) {
-  const size_t T = (size_t)N * L, d = W.width, H = W.heads, nl = W.layers;
+// `exact` (split-precision mode): every 16-bit operand buffer holds a hi|lo pair (twice the columns) and QKV / dO are fp32
+size_t tower_bytes(const TowerW& W, int N, int L, bool save, bool exact) {
+  const size_t T = (size_t)N * L, d = W.width, H = W.heads, nl = W.layers, X = exact ? 2 : 1;
   size_t b = 0;
   b += (save ? (2 * nl + 1) : 1) * align256(T * d * 4);             // x
-  b += align256(T * d * 2);                                          // h16
-  b += (save ? nl : 1) * align256(T * 3 * d * 2);                    // qkv
-  b += (save ? nl : 1) * align256(T * d * 2);                        // attn
+  b += align256(T * d * 2 * X);                                      // h16
+  b += (save ? nl : 1) * align256(T * 3 * d * 2 * X);                // qkv
+  b += (save ? nl : 1) * align256(T * d * 2 * X);                    // attn
   b += (save ? nl : 1) * align256((size_t)N * H * L * 4);            // lse
   b += (save ? nl : 1) * align256(T * 4 * d * 2);                    // u
-  b += align256(T * 4 * d * 2);                                      // a16
+  b += align256(T * 4 * d * 2 * X);                                  // a16
   if (save) {
-    b += 2 * align256(T * d * 4) + 3 * align256(T * d * 2) + align256(T * 4 * d * 2) + align256(T * 3 * d * 2);
+    b += 2 * align256(T * d * 4) + 2 * align256(T * d * 2 * X) + (align256(T * 4 * d * 2) + align256(T * 3 * d * 2)) * X;
     b += align256((size_t)N * H * L * 4) + 256;
   }
   return b + 4096;
 }
-void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool save, bool causal) {
-  const size_t T = (size_t)N * L, d = W.width, H = W.heads; const int nl = W.layers;
+void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool save, bool causal, bool exact) {
+  const size_t T = (size_t)N * L, d = W.width, H = W.heads, X = exact ? 2 : 1; const int nl = W.layers;
   st = TowerState();
-  st.N = N; st.L = L; st.d = (int)d; st.H = (int)H; st.layers = nl; st.saved = save; st.causal = causal;
+  st.N = N; st.L = L; st.d = (int)d; st.H = (int)H; st.layers = nl; st.saved = save; st.causal = causal; st.exact = exact;
   st.x.resize(2 * nl + 1); st.qkv.resize(nl); st.attn.resize(nl); st.u.resize(nl); st.lse.resize(nl); st.skip.assign(nl, 0);
   float* x0 = bp.take<float>(T * d);
   for (int i = 0; i < 2 * nl + 1; ++i) st.x[i] = (save && i > 0) ? bp.take<float>(T * d) : x0;
-  st.h16 = bp.take_bytes(T * d * 2);
+  st.h16 = bp.take_bytes(T * d * 2 * X);
   for (int l = 0; l < nl; ++l) {
     const bool fresh = save || l == 0;
-    st.qkv[l] = fresh ? bp.take_bytes(T * 3 * d * 2) : st.qkv[0];
-    st.attn[l] = fresh ? bp.take_bytes(T * d * 2) : st.attn[0];
+    st.qkv[l] = fresh ? bp.take_bytes(T * 3 * d * 2 * X) : st.qkv[0];
+    st.attn[l] = fresh ? bp.take_bytes(T * d * 2 * X) : st.attn[0];
     st.lse[l] = fresh ? bp.take<float>((size_t)N * H * L) : st.lse[0];
     st.u[l] = fresh ? bp.take_bytes(T * 4 * d * 2) : st.u[0];
   }
-  st.a16 = bp.take_bytes(T * 4 * d * 2);
+  st.a16 = bp.take_bytes(T * 4 * d * 2 * X);
   if (save) {
     st.dx32 = bp.take<float>(T * d);
-    st.dx16 = bp.take_bytes(T * d * 2); st.dh32 = bp.take<float>(T * d); st.dO16 = bp.take_bytes(T * d * 2);
-    st.du16 = bp.take_bytes(T * 4 * d * 2); st.dqkv16 = bp.take_bytes(T * 3 * d * 2);
+    st.dx16 = bp.take_bytes(T * d * 2 * X); st.dh32 = bp.take<float>(T * d); st.dO16 = bp.take_bytes(T * d * 2 * X);
+    st.du16 = bp.take_bytes(T * 4 * d * 2 * X); st.dqkv16 = bp.take_bytes(T * 3 * d * 2 * X);
     st.delta = bp.take<float>((size_t)N * H * L);
     st.scale_dev = bp.take<float>(4);   // {scale, 1/scale, amax scratch, pad}
   }
   st.valid = true;
 }
 
+// fp32 attention core of the split-precision mode: qkv32 [T,3d] -> O as a hi|lo pair [T,2d]
+int attn32_fwd(Engine* E, TowerState& st, int l, int q_rows, hipStream_t s) {
+  Attn32Args a{(const float*)st.qkv[l], st.attn[l], st.saved ? st.lse[l] : nullptr, st.N, st.L, st.H, st.causal ? 1 : 0, q_rows};
+  const double rows = q_rows > 0 ? (double)q_rows : (double)st.L;
+  ProfScope ps(E, s, PC_ATTN_FWD, 4.0 * rows * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0), (double)st.N * st.L * st.d * 16.0);
+  HIPCHK(E, launch_attn32_fwd(E->dt, a, s));
+  return 0;
+}
+int attn32_bwd(Engine* E, TowerState& st, int l, hipStream_t s) {
+  Attn32BwdArgs a{(const float*)st.qkv[l], st.attn[l], (const float*)st.dO16, st.lse[l], st.delta, st.dqkv16, st.N, st.L, st.H, st.causal ? 1 : 0};
+  ProfScope ps(E, s, PC_ATTN_BWD, 14.0 * st.L * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0), (double)st.N * st.L * st.d * 32.0);
+  HIPCHK(E, launch_attn32_bwd(E->dt, a, s));
+  return 0;
+}
+
+// Split-precision variant of block_fwd / block_bwd below: every GEMM A operand is a 16-bit hi|lo pair (~22 bits), the
+// attention core runs in fp32.  Used for towers that carry a gradient (and for every tower under MVLPT_PREC_SPLIT_ALL).
+int block_fwd_x(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
+  const Block& B = W.blocks[l];
+  const int T = st.N * st.L, d = st.d;
+  float* xin = st.x[2 * l]; float* xmid = st.x[2 * l + 1]; float* xout = st.x[2 * l + 2];
+  HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, B.ln1, st.h16, T, d, s, 1));
+  HIPCHK(E, gemm(E, EPI_STORE32, st.h16, B.qkv.w, T, 3 * d, d, B.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, 1));
+  if (int rc = attn32_fwd(E, st, l, 0, s)) return rc;
+  HIPCHK(E, gemm(E, EPI_RESID32, st.attn[l], B.o.w, T, d, d, B.o.b, nullptr, xin, xmid, nullptr, s, -1, 1));
+  HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, B.ln2, st.h16, T, d, s, 1));
+  HIPCHK(E, gemm(E, EPI_GELU_SPLIT, st.h16, B.fc.w, T, 4 * d, d, B.fc.b, nullptr, nullptr, st.a16, st.saved ? st.u[l] : nullptr, s, -1, 1));
+  HIPCHK(E, gemm(E, EPI_RESID32, st.a16, B.pr.w, T, d, 4 * d, B.pr.b, nullptr, xmid, xout, nullptr, s, -1, 1));
+  return 0;
+}
+int block_bwd_x(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
+  const Block& B = W.blocks[l];
+  const int T = st.N * st.L, d = st.d;
+  HIPCHK(E, gemm(E, EPI_GELUBWD_SPLIT, st.dx16, B.pr.wt, T, 4 * d, d, nullptr, st.u[l], nullptr, st.du16, nullptr, s, -1, 1));
+  HIPCHK(E, gemm(E, EPI_STORE32, st.du16, B.fc.wt, T, d, 4 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, 1));
+  HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l + 1], nullptr, 1, B.ln2, st.dx32, st.dx32, st.dx16, T, d, s, -1, 1));
+  HIPCHK(E, gemm(E, EPI_STORE32, st.dx16, B.o.wt, T, d, d, nullptr, nullptr, nullptr, st.dO16, nullptr, s, -1, 1));
+  if (int rc = attn32_bwd(E, st, l, s)) return rc;
+  HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, B.qkv.wt, T, d, 3 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, 1));
+  HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, B.ln1, st.dx32, st.dx32, st.dx16, T, d, s, -1, 1));
+  return 0;
+}
+
 // ResidualAttentionBlock.forward (clip/model.py:185-188) on token buffers
 int block_fwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
+  if (st.exact) return block_fwd_x(E, W, st, l, s);
   const Block& B = W.blocks[l];
   const int T = st.N * st.L, d = st.d;
   float* xin = st.x[2 * l]; float* xmid = st.x[2 * l + 1]; float* xout = st.x[2 * l + 2];
@@ -226,6 +279,7 @@ int block_fwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) 
 
 // dX-only backward of one block: dx32/dx16 hold d(block output) on entry and d(block input) on exit
 int block_bwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
+  if (st.exact) return block_bwd_x(E, W, st, l, s);
   const Block& B = W.blocks[l];
   const int T = st.N * st.L, d = st.d;
   HIPCHK(E, gemm(E, EPI_GELUBWD, st.dx16, B.pr.wt, T, 4 * d, d, nullptr, st.u[l], nullptr, st.du16, nullptr, s));
@@ -355,6 +409,15 @@ int mvlpt_create(const MvlptArch* a, void** handle) {
   return 0;
 }
 
+int mvlpt_set_precision(void* h, int mode) {
+  Engine* E = (Engine*)h;
+  if (!E) return MVLPT_ERR_ARG;
+  if (mode != MVLPT_PREC_FAST && mode != MVLPT_PREC_SPLIT_GRAD && mode != MVLPT_PREC_SPLIT_ALL)
+    return fail(E, MVLPT_ERR_ARG, "set_precision: unknown mode");
+  E->prec_mode = mode;
+  return 0;
+}
+
 int mvlpt_destroy(void* h) {
   if (!h) return 0;
   Engine* E = (Engine*)h;
@@ -457,9 +520,11 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   const int Lv = 1 + n_vpt + G2;
   if (Lv > attn_max_len()) return fail(E, MVLPT_ERR_UNSUPPORTED, "image_fwd: sequence length > 256 not supported yet");
   const bool save = save_for_bwd != 0;
+  const bool exact = E->prec_mode == MVLPT_PREC_SPLIT_ALL || (E->prec_mode == MVLPT_PREC_SPLIT_GRAD && save);
+  const size_t X = exact ? 2 : 1;
   const size_t npatch = (size_t)B * G2;
-  size_t need = tower_bytes(E->vis, B, Lv, save) + align256(npatch * E->Kp * 2) + align256(npatch * dv * 4) +
-                7 * align256((size_t)B * dv * 4) + 4 * align256((size_t)B * dv * 2) + 3 * align256((size_t)B * dv * 8) + 4096;
+  size_t need = tower_bytes(E->vis, B, Lv, save, exact) + align256(npatch * E->Kp * 2) + align256(npatch * dv * 4) +
+                7 * align256((size_t)B * dv * 4) + 4 * align256((size_t)B * dv * 2 * X) + 3 * align256((size_t)B * dv * 8 * X) + 4096;
   E->vs.valid = false;
   HIPCHK(E, E->vis_ws.reserve(need));
   Bump bp; bp.base = (char*)E->vis_ws.p; bp.cap = E->vis_ws.cap;
@@ -468,14 +533,14 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   E->cls32 = bp.take<float>((size_t)B * dv);
   E->dcls32 = bp.take<float>((size_t)B * dv);
   E->xc32 = bp.take<float>((size_t)B * dv);
-  E->ac16 = bp.take_bytes((size_t)B * dv * 2); E->hc16 = bp.take_bytes((size_t)B * dv * 2);
-  E->gc16 = bp.take_bytes((size_t)B * dv * 4 * 2);
+  E->ac16 = bp.take_bytes((size_t)B * dv * 2 * X); E->hc16 = bp.take_bytes((size_t)B * dv * 2 * X);
+  E->gc16 = bp.take_bytes((size_t)B * dv * 4 * 2 * X);
   E->xcm32 = bp.take<float>((size_t)B * dv); E->xco32 = bp.take<float>((size_t)B * dv);
   E->dxc32 = bp.take<float>((size_t)B * dv); E->dhc32 = bp.take<float>((size_t)B * dv);
-  E->dxc16 = bp.take_bytes((size_t)B * dv * 2); E->dOc16 = bp.take_bytes((size_t)B * dv * 2);
-  E->uc16 = bp.take_bytes((size_t)B * dv * 4 * 2); E->duc16 = bp.take_bytes((size_t)B * dv * 4 * 2);
+  E->dxc16 = bp.take_bytes((size_t)B * dv * 2 * X); E->dOc16 = bp.take_bytes((size_t)B * dv * 2 * X);
+  E->uc16 = bp.take_bytes((size_t)B * dv * 4 * 2); E->duc16 = bp.take_bytes((size_t)B * dv * 4 * 2 * X);
   E->v_cls_last = false;
-  carve_tower(bp, E->vis, E->vs, B, Lv, save, false);
+  carve_tower(bp, E->vis, E->vs, B, Lv, save, false, exact);
   TowerState& st = E->vs;
   E->vB = B; E->v_nvpt = n_vpt; E->v_ndeep = n_deep;
 
@@ -514,20 +579,26 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
     float* xmid = save ? E->xcm32 : E->xc32;     // kept for the backward: LN2 input ...
     float* xout = save ? E->xco32 : E->xc32;     // ... and ln_post input
     E->v_cls_last = save;
-    HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dv, s));
-    HIPCHK(E, gemm(E, EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dv, dv, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s));
-    {
+    const int xs = st.exact ? 1 : 0;      // split-precision operands (hi|lo pairs, twice the columns) + fp32 attention
+    HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dv, s, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE32 : EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dv, dv, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
+    if (xs) {
+      // only the CLS rows of the attention output are produced: the backward (delta = rowsum(dO * O) over EVERY row, with
+      // dO = 0 off the CLS rows) must not meet uninitialised memory there
+      if (save) HIPCHK(E, launch_zero(st.attn[l], (size_t)T * dv * 4, s));
+      if (int rc = attn32_fwd(E, st, l, 1, s)) return rc;
+    } else {
       AttnArgs a{st.qkv[l], st.attn[l], save ? st.lse[l] : nullptr, st.N, st.L, st.H, 0, 1};
       ProfScope ps(E, s, PC_ATTN_FWD, 4.0 * st.L * 64.0 * st.N * st.H, (double)T * dv * 2.0 * 2.0);
       HIPCHK(E, launch_attn_fwd(E->dt, a, s));
     }
     { ProfScope ps(E, s, PC_GLUE, 0, (double)B * dv * 12.0);
-      HIPCHK(E, hipMemcpy2DAsync(E->ac16, (size_t)dv * 2, st.attn[l], (size_t)Lv * dv * 2, (size_t)dv * 2, B, hipMemcpyDeviceToDevice, s));
-      HIPCHK(E, hipMemcpy2DAsync(E->xc32, (size_t)dv * 4, xin, (size_t)Lv * dv * 4, (size_t)dv * 4, B, hipMemcpyDeviceToDevice, s)); }
-    HIPCHK(E, gemm(E, EPI_RESID32, E->ac16, Bk.o.w, B, dv, dv, Bk.o.b, nullptr, E->xc32, xmid, nullptr, s));
-    HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, Bk.ln2, E->hc16, B, dv, s));
-    HIPCHK(E, gemm(E, EPI_GELU, E->hc16, Bk.fc.w, B, 4 * dv, dv, Bk.fc.b, nullptr, nullptr, E->gc16, save ? E->uc16 : nullptr, s));
-    HIPCHK(E, gemm(E, EPI_RESID32, E->gc16, Bk.pr.w, B, dv, 4 * dv, Bk.pr.b, nullptr, xmid, xout, nullptr, s));
+      HIPCHK(E, launch_copy_rows_strided(st.attn[l], E->ac16, B, (size_t)Lv * dv * 2 * X, (size_t)dv * 2 * X, (int)(dv * 2 * X), s));
+      HIPCHK(E, launch_copy_rows_strided(xin, E->xc32, B, (size_t)Lv * dv * 4, (size_t)dv * 4, dv * 4, s)); }
+    HIPCHK(E, gemm(E, EPI_RESID32, E->ac16, Bk.o.w, B, dv, dv, Bk.o.b, nullptr, E->xc32, xmid, nullptr, s, -1, xs));
+    HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, Bk.ln2, E->hc16, B, dv, s, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_GELU_SPLIT : EPI_GELU, E->hc16, Bk.fc.w, B, 4 * dv, dv, Bk.fc.b, nullptr, nullptr, E->gc16, save ? E->uc16 : nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, EPI_RESID32, E->gc16, Bk.pr.w, B, dv, 4 * dv, Bk.pr.b, nullptr, xmid, xout, nullptr, s, -1, xs));
     HIPCHK(E, ln_fwd(E, DT_F32, xout, nullptr, 1, E->ln_post, E->cls32, B, dv, s));
   } else
   // ln_post on the CLS row, then @ proj   (trainers/mvlpt.py:88-91)
@@ -553,33 +624,42 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
   { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 4.0);
     HIPCHK(E, launch_zero(st.dx32, T * dv * 4, s)); }
   int l_top = st.layers - 1;
+  const int xs = st.exact ? 1 : 0;
   if (E->v_cls_last) {
     // last block, CLS rows only (see mvlpt_image_fwd): ln_post, MLP, ln_2, out-proj on B compact rows; the attention
     // backward of a single query per head; then the full-width QKV^T GEMM and ln_1 (keys / values of every token)
     const int l = st.layers - 1;
     const Block& Bk = E->vis.blocks[l];
     const int Ti = (int)T;
-    HIPCHK(E, ln_bwd(E, E->dcls32, DT_F32, E->xco32, nullptr, 1, E->ln_post, nullptr, E->dxc32, E->dxc16, B, dv, s));
-    HIPCHK(E, gemm(E, EPI_GELUBWD, E->dxc16, Bk.pr.wt, B, 4 * dv, dv, nullptr, E->uc16, nullptr, E->duc16, nullptr, s));
-    HIPCHK(E, gemm(E, EPI_STORE32, E->duc16, Bk.fc.wt, B, dv, 4 * dv, nullptr, nullptr, nullptr, E->dhc32, nullptr, s));
-    HIPCHK(E, ln_bwd(E, E->dhc32, DT_F32, E->xcm32, nullptr, 1, Bk.ln2, E->dxc32, E->dxc32, E->dxc16, B, dv, s));
-    HIPCHK(E, gemm(E, EPI_STORE16, E->dxc16, Bk.o.wt, B, dv, dv, nullptr, nullptr, nullptr, E->dOc16, nullptr, s));
-    { ProfScope ps(E, s, PC_ATTN_BWD, 10.0 * st.L * 64.0 * st.N * st.H, (double)T * dv * 2.0 * 5.0);
+    HIPCHK(E, ln_bwd(E, E->dcls32, DT_F32, E->xco32, nullptr, 1, E->ln_post, nullptr, E->dxc32, E->dxc16, B, dv, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_GELUBWD_SPLIT : EPI_GELUBWD, E->dxc16, Bk.pr.wt, B, 4 * dv, dv, nullptr, E->uc16, nullptr, E->duc16, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, EPI_STORE32, E->duc16, Bk.fc.wt, B, dv, 4 * dv, nullptr, nullptr, nullptr, E->dhc32, nullptr, s, -1, xs));
+    HIPCHK(E, ln_bwd(E, E->dhc32, DT_F32, E->xcm32, nullptr, 1, Bk.ln2, E->dxc32, E->dxc32, E->dxc16, B, dv, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE32 : EPI_STORE16, E->dxc16, Bk.o.wt, B, dv, dv, nullptr, nullptr, nullptr, E->dOc16, nullptr, s, -1, xs));
+    if (xs) {
+      // fp32 attention backward at full width on a dO that is zero except for the CLS rows
+      { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 4.0);
+        HIPCHK(E, launch_zero(st.dO16, T * dv * 4, s));
+        HIPCHK(E, launch_copy_rows_strided(E->dOc16, st.dO16, B, (size_t)dv * 4, (size_t)Lv * dv * 4, dv * 4, s)); }
+      if (int rc = attn32_bwd(E, st, l, s)) return rc;
+    } else {
+      ProfScope ps(E, s, PC_ATTN_BWD, 10.0 * st.L * 64.0 * st.N * st.H, (double)T * dv * 2.0 * 5.0);
       HIPCHK(E, launch_attn_bwd_cls(E->dt, st.qkv[l], E->ac16, E->dOc16, st.lse[l], st.dqkv16, st.N, st.L, st.H, s)); }
     { ProfScope ps(E, s, PC_GLUE, 0, (double)B * dv * 8.0);      // residual path: d(block input) of the CLS rows
-      HIPCHK(E, hipMemcpy2DAsync(st.dx32, (size_t)Lv * dv * 4, E->dxc32, (size_t)dv * 4, (size_t)dv * 4, B, hipMemcpyDeviceToDevice, s)); }
-    HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, Bk.qkv.wt, Ti, dv, 3 * dv, nullptr, nullptr, nullptr, st.dh32, nullptr, s));
-    HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, Bk.ln1, st.dx32, st.dx32, st.dx16, Ti, dv, s));
+      HIPCHK(E, launch_copy_rows_strided(E->dxc32, st.dx32, B, (size_t)dv * 4, (size_t)Lv * dv * 4, dv * 4, s)); }
+    HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, Bk.qkv.wt, Ti, dv, 3 * dv, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, xs));
+    HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, Bk.ln1, st.dx32, st.dx32, st.dx16, Ti, dv, s, -1, xs));
     if (l > 0 && E->v_ndeep > 0 && l <= E->v_ndeep) {
       ProfScope ps(E, s, PC_GLUE, 0, (double)B * n * dv * 10.0);
       HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt_deep + (size_t)(l - 1) * n * dv,
-                                          st.scale_dev, 1, s));
+                                          st.scale_dev, 1, s, xs));
     }
     l_top = l - 1;
   } else {
     HIPCHK(E, ln_bwd(E, E->dcls32, DT_F32, st.x[2 * st.layers], nullptr, Lv, E->ln_post, nullptr, st.dx32, nullptr, B, dv, s));
     { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 6.0);
-      HIPCHK(E, launch_cast_f32_to16(E->dt, st.dx32, st.dx16, T * dv, nullptr, s)); }
+      if (xs) HIPCHK(E, launch_cast_f32_split(E->dt, st.dx32, st.dx16, T, dv, nullptr, s));
+      else HIPCHK(E, launch_cast_f32_to16(E->dt, st.dx32, st.dx16, T * dv, nullptr, s)); }
   }
   for (int l = l_top; l >= 0; --l) {
     if (st.skip[l]) continue;
@@ -587,7 +667,7 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
     if (l > 0 && E->v_ndeep > 0 && l <= E->v_ndeep) {
       ProfScope ps(E, s, PC_GLUE, 0, (double)B * n * dv * 10.0);
       HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt_deep + (size_t)(l - 1) * n * dv,
-                                          st.scale_dev, 1, s));
+                                          st.scale_dev, 1, s, xs));
     }
   }
   if (n > 0) {
@@ -612,8 +692,10 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
   hipStream_t s = (hipStream_t)stream;
   const int dtw = A.text_width, e = A.embed_dim;
   const bool save = save_for_bwd != 0;
-  size_t need = tower_bytes(E->txt, C, L, save) + 7 * align256((size_t)C * dtw * 4) + 4 * align256((size_t)C * dtw * 2) +
-                3 * align256((size_t)C * dtw * 8) + align256((size_t)C * 4) + align256((size_t)C * (n_ctx > 0 ? n_ctx : 1) * 4) + 4096;
+  const bool exact = E->prec_mode == MVLPT_PREC_SPLIT_ALL || (E->prec_mode == MVLPT_PREC_SPLIT_GRAD && save);
+  const size_t X = exact ? 2 : 1;
+  size_t need = tower_bytes(E->txt, C, L, save, exact) + 7 * align256((size_t)C * dtw * 4) + 4 * align256((size_t)C * dtw * 2 * X) +
+                3 * align256((size_t)C * dtw * 8 * X) + align256((size_t)C * 4) + align256((size_t)C * (n_ctx > 0 ? n_ctx : 1) * 4) + 4096;
   E->ts.valid = false;
   HIPCHK(E, E->txt_ws.reserve(need));
   Bump bp; bp.base = (char*)E->txt_ws.p; bp.cap = E->txt_ws.cap;
@@ -623,11 +705,11 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
   E->ctx_pos = bp.take<int32_t>((size_t)C * (n_ctx > 0 ? n_ctx : 1));
   E->txc32 = bp.take<float>((size_t)C * dtw); E->txm32 = bp.take<float>((size_t)C * dtw); E->txo32 = bp.take<float>((size_t)C * dtw);
   E->tdxc32 = bp.take<float>((size_t)C * dtw); E->tdhc32 = bp.take<float>((size_t)C * dtw);
-  E->tac16 = bp.take_bytes((size_t)C * dtw * 2); E->thc16 = bp.take_bytes((size_t)C * dtw * 2);
-  E->tdxc16 = bp.take_bytes((size_t)C * dtw * 2); E->tdOc16 = bp.take_bytes((size_t)C * dtw * 2);
-  E->tgc16 = bp.take_bytes((size_t)C * dtw * 8); E->tuc16 = bp.take_bytes((size_t)C * dtw * 8); E->tduc16 = bp.take_bytes((size_t)C * dtw * 8);
+  E->tac16 = bp.take_bytes((size_t)C * dtw * 2 * X); E->thc16 = bp.take_bytes((size_t)C * dtw * 2 * X);
+  E->tdxc16 = bp.take_bytes((size_t)C * dtw * 2 * X); E->tdOc16 = bp.take_bytes((size_t)C * dtw * 2 * X);
+  E->tgc16 = bp.take_bytes((size_t)C * dtw * 8 * X); E->tuc16 = bp.take_bytes((size_t)C * dtw * 8); E->tduc16 = bp.take_bytes((size_t)C * dtw * 8 * X);
   E->t_eot_last = false;
-  carve_tower(bp, E->txt, E->ts, C, L, save, true);
+  carve_tower(bp, E->txt, E->ts, C, L, save, true, exact);
   TowerState& st = E->ts;
   E->tC = C; E->tL = L; E->t_nctx = n_ctx; E->t_per_class = ctx_per_class;
   { ProfScope ps(E, s, PC_GLUE, 0, (double)C * L * dtw * 12.0);
@@ -645,20 +727,23 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
     const int T = C * L;
     float* xin = st.x[2 * l];
     E->t_eot_last = save;
-    HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dtw, s));
-    HIPCHK(E, gemm(E, EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dtw, dtw, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s));
-    {
+    const int xs = st.exact ? 1 : 0;
+    HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dtw, s, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE32 : EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dtw, dtw, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
+    if (xs) {
+      if (int rc = attn32_fwd(E, st, l, 0, s)) return rc;
+    } else {
       AttnArgs a{st.qkv[l], st.attn[l], save ? st.lse[l] : nullptr, st.N, st.L, st.H, 1};
       ProfScope ps(E, s, PC_ATTN_FWD, 2.0 * st.L * st.L * 64.0 * st.N * st.H, (double)T * dtw * 2.0 * 4.0);
       HIPCHK(E, launch_attn_fwd(E->dt, a, s));
     }
     { ProfScope ps(E, s, PC_GLUE, 0, (double)C * dtw * 12.0);
-      HIPCHK(E, launch_copy_rows(st.attn[l], E->tac16, E->eot_rows, C, dtw * 2, 0, s));
+      HIPCHK(E, launch_copy_rows(st.attn[l], E->tac16, E->eot_rows, C, (int)(dtw * 2 * X), 0, s));
       HIPCHK(E, launch_copy_rows(xin, E->txc32, E->eot_rows, C, dtw * 4, 0, s)); }
-    HIPCHK(E, gemm(E, EPI_RESID32, E->tac16, Bk.o.w, C, dtw, dtw, Bk.o.b, nullptr, E->txc32, E->txm32, nullptr, s));
-    HIPCHK(E, ln_fwd(E, E->dt, E->txm32, nullptr, 1, Bk.ln2, E->thc16, C, dtw, s));
-    HIPCHK(E, gemm(E, EPI_GELU, E->thc16, Bk.fc.w, C, 4 * dtw, dtw, Bk.fc.b, nullptr, nullptr, E->tgc16, save ? E->tuc16 : nullptr, s));
-    HIPCHK(E, gemm(E, EPI_RESID32, E->tgc16, Bk.pr.w, C, dtw, 4 * dtw, Bk.pr.b, nullptr, E->txm32, E->txo32, nullptr, s));
+    HIPCHK(E, gemm(E, EPI_RESID32, E->tac16, Bk.o.w, C, dtw, dtw, Bk.o.b, nullptr, E->txc32, E->txm32, nullptr, s, -1, xs));
+    HIPCHK(E, ln_fwd(E, E->dt, E->txm32, nullptr, 1, Bk.ln2, E->thc16, C, dtw, s, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_GELU_SPLIT : EPI_GELU, E->thc16, Bk.fc.w, C, 4 * dtw, dtw, Bk.fc.b, nullptr, nullptr, E->tgc16, save ? E->tuc16 : nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, EPI_RESID32, E->tgc16, Bk.pr.w, C, dtw, 4 * dtw, Bk.pr.b, nullptr, E->txm32, E->txo32, nullptr, s, -1, xs));
     HIPCHK(E, ln_fwd(E, DT_F32, E->txo32, nullptr, 1, E->ln_final, E->eot32, C, dtw, s));
   }
   { ProfScope ps(E, s, PC_HEAD, 2.0 * C * e * dtw, 4.0 * ((double)C * dtw + (double)e * dtw + (double)C * e));
@@ -688,22 +773,26 @@ int mvlpt_text_bwd(void* h, const float* dfeat, float* dctx, mvlpt_stream_t stre
     const int l = st.layers - 1;
     const Block& Bk = E->txt.blocks[l];
     const int Ti = (int)T;
-    HIPCHK(E, ln_bwd(E, E->deot32, DT_F32, E->txo32, nullptr, 1, E->ln_final, nullptr, E->tdxc32, E->tdxc16, C, dtw, s));
-    HIPCHK(E, gemm(E, EPI_GELUBWD, E->tdxc16, Bk.pr.wt, C, 4 * dtw, dtw, nullptr, E->tuc16, nullptr, E->tduc16, nullptr, s));
-    HIPCHK(E, gemm(E, EPI_STORE32, E->tduc16, Bk.fc.wt, C, dtw, 4 * dtw, nullptr, nullptr, nullptr, E->tdhc32, nullptr, s));
-    HIPCHK(E, ln_bwd(E, E->tdhc32, DT_F32, E->txm32, nullptr, 1, Bk.ln2, E->tdxc32, E->tdxc32, E->tdxc16, C, dtw, s));
-    HIPCHK(E, gemm(E, EPI_STORE16, E->tdxc16, Bk.o.wt, C, dtw, dtw, nullptr, nullptr, nullptr, E->tdOc16, nullptr, s));
+    const int xs = st.exact ? 1 : 0;
+    const size_t X = xs ? 2 : 1;
+    HIPCHK(E, ln_bwd(E, E->deot32, DT_F32, E->txo32, nullptr, 1, E->ln_final, nullptr, E->tdxc32, E->tdxc16, C, dtw, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_GELUBWD_SPLIT : EPI_GELUBWD, E->tdxc16, Bk.pr.wt, C, 4 * dtw, dtw, nullptr, E->tuc16, nullptr, E->tduc16, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, EPI_STORE32, E->tduc16, Bk.fc.wt, C, dtw, 4 * dtw, nullptr, nullptr, nullptr, E->tdhc32, nullptr, s, -1, xs));
+    HIPCHK(E, ln_bwd(E, E->tdhc32, DT_F32, E->txm32, nullptr, 1, Bk.ln2, E->tdxc32, E->tdxc32, E->tdxc16, C, dtw, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE32 : EPI_STORE16, E->tdxc16, Bk.o.wt, C, dtw, dtw, nullptr, nullptr, nullptr, E->tdOc16, nullptr, s, -1, xs));
     { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dtw * 2.0);
-      HIPCHK(E, launch_zero(st.dO16, T * dtw * 2, s));
-      HIPCHK(E, launch_copy_rows(E->tdOc16, st.dO16, E->eot_rows, C, dtw * 2, 1, s));
+      HIPCHK(E, launch_zero(st.dO16, T * dtw * 2 * X, s));      // (exact: dO is fp32)
+      HIPCHK(E, launch_copy_rows(E->tdOc16, st.dO16, E->eot_rows, C, (int)(dtw * 2 * X), 1, s));
       HIPCHK(E, launch_copy_rows(E->tdxc32, st.dx32, E->eot_rows, C, dtw * 4, 1, s)); }     // residual path (dx32 was zeroed)
-    {
+    if (xs) {
+      if (int rc = attn32_bwd(E, st, l, s)) return rc;
+    } else {
       AttnBwdArgs a{st.qkv[l], st.attn[l], st.dO16, st.lse[l], st.delta, st.dqkv16, st.N, st.L, st.H, 1};
       ProfScope ps(E, s, PC_ATTN_BWD, 7.0 * st.L * st.L * 64.0 * st.N * st.H, (double)T * dtw * 2.0 * 8.0);
       HIPCHK(E, launch_attn_bwd(E->dt, a, s));
     }
-    HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, Bk.qkv.wt, Ti, dtw, 3 * dtw, nullptr, nullptr, nullptr, st.dh32, nullptr, s));
-    HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, Bk.ln1, st.dx32, st.dx32, st.dx16, Ti, dtw, s));
+    HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, Bk.qkv.wt, Ti, dtw, 3 * dtw, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, xs));
+    HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, Bk.ln1, st.dx32, st.dx32, st.dx16, Ti, dtw, s, -1, xs));
   }
   for (int l = st.layers - 2; l >= 0; --l)
     if (int rc = block_bwd(E, E->txt, st, l, s)) return rc;
@@ -787,6 +876,40 @@ int mvlpt_op_gemm(int dtype, int epi, const void* A, const void* Bt, int M, int 
     (void)hipFree(tr);
   }
 #endif
+  return 0;
+}
+int mvlpt_op_gemm_split(int dtype, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
+                        const float* resid, void* out, void* out2, mvlpt_stream_t stream) {
+  GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
+  g.a_split = 1;
+  OPCHK(launch_gemm(dtype, epi, g, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_layernorm_fwd_split(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
+                                 mvlpt_stream_t stream) {
+  if (out_dtype == DT_F32) { g_create_err = "layernorm_fwd_split: 16-bit output only"; return MVLPT_ERR_ARG; }
+  LnFwdArgs a{x, nullptr, 1, gamma, beta, y, rows, d};
+  a.split = 1;
+  OPCHK(launch_ln_fwd(out_dtype, a, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_layernorm_bwd_split(int dtype, const void* dy, const float* x, const float* gamma, const float* resid, float* out32,
+                                 void* out16, int rows, int d, mvlpt_stream_t stream) {
+  LnBwdArgs a{dy, DT_F32, x, nullptr, 1, gamma, resid, out32, out16, rows, d};
+  a.split = 1;
+  OPCHK(launch_ln_bwd(dtype, a, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_attention32_fwd(int dtype, const float* qkv, void* out, float* lse, int N, int L, int H, int causal, int q_rows,
+                             mvlpt_stream_t stream) {
+  Attn32Args a{qkv, out, lse, N, L, H, causal, q_rows};
+  OPCHK(launch_attn32_fwd(dtype, a, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_attention32_bwd(int dtype, const float* qkv, const void* out, const float* dout, const float* lse, float* delta,
+                             void* dqkv, int N, int L, int H, int causal, mvlpt_stream_t stream) {
+  Attn32BwdArgs a{qkv, out, dout, lse, delta, dqkv, N, L, H, causal};
+  OPCHK(launch_attn32_bwd(dtype, a, (hipStream_t)stream));
   return 0;
 }
 int mvlpt_op_layernorm_fwd(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
@@ -882,6 +1005,7 @@ int mvlpt_profile_end(void* h, MvlptKernelStat* stats, int max_stats) {
     float ms = 0.f, t0 = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
     acc[r.cls].launches += 1; acc[r.cls].ms += ms; acc[r.cls].flops += r.flops; acc[r.cls].bytes += r.bytes;
+    acc[r.cls].flops_executed += r.flops_exec;
     if (r.a == ref || hipEventElapsedTime(&t0, ref, r.a) == hipSuccess) iv[r.cls].push_back({t0, t0 + ms});
   }
   for (int c = 0; c < PC_COUNT; ++c) {                    // union of the intervals per class

@@ -119,7 +119,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
     // load while LDS-DMA is in flight, and that wait would also drain the stores issued before it.
     f32x4 rv[4][4];
     v4 uv[4][4];
-    if constexpr (EPI == EPI_RESID32 || EPI == EPI_GELUBWD) {
+    if constexpr (EPI == EPI_RESID32 || EPI == EPI_GELUBWD || EPI == EPI_GELUBWD_SPLIT) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -149,6 +149,22 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
 #pragma unroll
           for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(v[e] * quick_gelu_grad(to_f32<T>(uv[i][it][e])));
           if (m < M) __builtin_nontemporal_store(w, (v4*)((T*)g.out + o));
+        } else if constexpr (EPI == EPI_GELU_SPLIT || EPI == EPI_GELUBWD_SPLIT) {
+          v4 hi, lo, u16;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float r;
+            if constexpr (EPI == EPI_GELU_SPLIT) { r = quick_gelu(v[e]); u16[e] = from_f32<T>(v[e]); }
+            else r = v[e] * quick_gelu_grad(to_f32<T>(uv[i][it][e]));
+            hi[e] = from_f32<T>(r);
+            lo[e] = from_f32<T>(r - to_f32<T>(hi[e]));
+          }
+          if (m < M) {
+            T* row = (T*)g.out + (size_t)m * (2 * N) + nbase + c * 4;
+            __builtin_nontemporal_store(hi, (v4*)row);
+            __builtin_nontemporal_store(lo, (v4*)(row + N));
+            if constexpr (EPI == EPI_GELU_SPLIT) { if (g.out2) __builtin_nontemporal_store(u16, (v4*)((T*)g.out2 + o)); }
+          }
         } else {  // EPI_STORE32
           if (m < M) __builtin_nontemporal_store(v, (f32x4*)((float*)g.out + o));
         }
@@ -176,6 +192,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = g.M, N = g.N, K = g.K;
+  const int lda = g.a_split ? 2 * K : K;
   const T* __restrict__ A = (const T*)g.A;
   const T* __restrict__ Bt = (const T*)g.Bt;
 #ifdef MVLPT_GEMM_TRACE
@@ -210,7 +227,7 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       int ar = m0 + (i * NW + wave) * 8 + srow; ar = ar < M ? ar : M - 1;   // edge rows are re-read, never stored
-      ap[i] = A + (size_t)ar * K + scol;
+      ap[i] = A + (size_t)ar * lda + scol;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -219,7 +236,8 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
     }
   };
   // load cursor (runs NS-1 K-stages ahead of the compute cursor, across tile boundaries)
-  const int nk = K / BK;
+  // split-precision A ([M,2K] = [hi | lo], kernels.h): 2K/BK stages, the Bt K-index wraps after K/BK of them
+  const int nkb = K / BK, nk = g.a_split ? 2 * nkb : nkb;
   int lround = 0, lt = tile_of(0), lkt = 0, lslot = 0;
   if (lt >= ntiles) return;
   set_ptrs(lt);
@@ -228,8 +246,9 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
     char* base = smem + lslot * STAGE;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) glds16(ap[i] + lkt * BK, base + (i * NW + wave) * 1024);
+    const int bk = (lkt >= nkb ? lkt - nkb : lkt) * BK;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) glds16(bp[i] + lkt * BK, base + A_BYTES + (i * NW + wave) * 1024);
+    for (int i = 0; i < B_IT; ++i) glds16(bp[i] + bk, base + A_BYTES + (i * NW + wave) * 1024);
     lslot = lslot + 1 == NS ? 0 : lslot + 1;
     if (++lkt == nk) {
       lkt = 0;
@@ -388,6 +407,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_phased_kernel(GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool trail = wave >= NW / 2;
   const int M = g.M, N = g.N, K = g.K;
+  const int lda = g.a_split ? 2 * K : K;
   const T* __restrict__ A = (const T*)g.A;
   const T* __restrict__ Bt = (const T*)g.Bt;
 
@@ -409,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_phased_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       int ar = m0 + (i * NW + wave) * 8 + srow; ar = ar < M ? ar : M - 1;
-      ap[i] = A + (size_t)ar * K + scol;
+      ap[i] = A + (size_t)ar * lda + scol;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -417,7 +437,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_phased_kernel(GemmArgs g) {
       bp[i] = Bt + (size_t)br * K + scol;
     }
   };
-  const int nk = K / BK;
+  // split-precision A ([M,2K] = [hi | lo], kernels.h): 2K/BK stages, the Bt K-index wraps after K/BK of them
+  const int nkb = K / BK, nk = g.a_split ? 2 * nkb : nkb;
   int lround = 0, lt = tile_of(0), lkt = 0, lslot = 0;
   if (lt >= ntiles) return;
   set_ptrs(lt);
@@ -426,8 +447,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_phased_kernel(GemmArgs g) {
     char* base = smem + lslot * STAGE;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) glds16(ap[i] + lkt * BK, base + (i * NW + wave) * 1024);
+    const int bk = (lkt >= nkb ? lkt - nkb : lkt) * BK;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) glds16(bp[i] + lkt * BK, base + A_BYTES + (i * NW + wave) * 1024);
+    for (int i = 0; i < B_IT; ++i) glds16(bp[i] + bk, base + A_BYTES + (i * NW + wave) * 1024);
     lslot = lslot + 1 == NS ? 0 : lslot + 1;
     if (++lkt == nk) {
       lkt = 0;
@@ -566,8 +588,8 @@ static int num_cus() {
 template <int EPI>
 static GemmArgs row_slice(const GemmArgs& g, int m_lo, int rows) {
   GemmArgs r = g;
-  const size_t ok = (size_t)m_lo * g.K, on = (size_t)m_lo * g.N;
-  constexpr size_t OB = (EPI == EPI_RESID32 || EPI == EPI_STORE32) ? 4 : 2;
+  const size_t ok = (size_t)m_lo * g.K * (g.a_split ? 2 : 1), on = (size_t)m_lo * g.N;
+  constexpr size_t OB = (EPI == EPI_RESID32 || EPI == EPI_STORE32 || EPI == EPI_GELU_SPLIT || EPI == EPI_GELUBWD_SPLIT) ? 4 : 2;
   r.A = (const char*)g.A + ok * 2;
   r.M = rows;
   r.out = (char*)g.out + on * OB;
@@ -588,8 +610,9 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   static const int phased = getenv("MVLPT_GEMM_PHASED") ? atoi(getenv("MVLPT_GEMM_PHASED")) : 2;   // 0 off, 1 all, 2 long K
   // 256x256 needs >= 4 rounds of tiles, or >= 2 rounds when K is long (a ragged last round then costs less than the
   // smaller geometry's extra LDS traffic: N = 768, K = 3072: 315 -> 297 us with 2.3 rounds)
-  const bool big = g.N % 256 == 0 && (t256 >= 1024 || (t256 >= 512 && g.K >= 2048));
-  if (t128 >= 384 && (phased == 1 || (phased == 2 && g.K >= 2048 && !big))) {
+  const int Keff = g.a_split ? 2 * g.K : g.K;
+  const bool big = g.N % 256 == 0 && (t256 >= 1024 || (t256 >= 512 && Keff >= 2048));
+  if (t128 >= 384 && (phased == 1 || (phased == 2 && Keff >= 2048 && !big))) {
     *tile_m = 256; *tile_n = 128;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_phased<T, EPI>(g, s, ea, eb);
   }
@@ -652,6 +675,8 @@ static hipError_t launch_epi(const GemmArgs& g, int epi, hipStream_t s, hipEvent
     case EPI_RESID32: return launch_t<T, EPI_RESID32>(g, s, ea, eb);
     case EPI_GELUBWD: return launch_t<T, EPI_GELUBWD>(g, s, ea, eb);
     case EPI_STORE32: return launch_t<T, EPI_STORE32>(g, s, ea, eb);
+    case EPI_GELU_SPLIT: return launch_t<T, EPI_GELU_SPLIT>(g, s, ea, eb);
+    case EPI_GELUBWD_SPLIT: return launch_t<T, EPI_GELUBWD_SPLIT>(g, s, ea, eb);
   }
   return hipErrorInvalidValue;
 }
@@ -660,7 +685,7 @@ static hipError_t launch_epi(const GemmArgs& g, int epi, hipStream_t s, hipEvent
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N % 128) != 0) return hipErrorInvalidValue;
   if (epi == EPI_RESID32 && !g.resid) return hipErrorInvalidValue;
-  if (epi == EPI_GELUBWD && !g.aux) return hipErrorInvalidValue;
+  if ((epi == EPI_GELUBWD || epi == EPI_GELUBWD_SPLIT) && !g.aux) return hipErrorInvalidValue;
   if (dtype == DT_F16) return launch_epi<f16>(g, epi, s, ea, eb);
   if (dtype == DT_BF16) return launch_epi<bf16>(g, epi, s, ea, eb);
   return hipErrorInvalidValue;

@@ -31,6 +31,33 @@ hipError_t launch_cast_f32_to16(int dtype, const float* in, void* out, size_t n,
   return hipGetLastError();
 }
 
+// fp32 [rows, d] -> 16-bit pair [rows, 2d] = [hi | lo]  (split-precision A operand, GemmArgs::a_split)
+template <typename T>
+__global__ void cast_split_kernel(const float* __restrict__ in, T* __restrict__ out, size_t rows, int d4, const float* scale_dev) {
+  const float sc = scale_dev ? scale_dev[0] : 1.0f;
+  const size_t n4 = rows * d4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / d4; const int c = (int)(i - r * d4) * 4;
+    const f32x4 v = *(const f32x4*)(in + i * 4) * sc;
+    typename Vec<T>::v4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hi[e] = (T)v[e]; lo[e] = (T)(v[e] - (float)hi[e]); }
+    T* row = out + r * (size_t)(8 * d4);
+    *(typename Vec<T>::v4*)(row + c) = hi;
+    *(typename Vec<T>::v4*)(row + 4 * d4 + c) = lo;
+  }
+}
+hipError_t launch_cast_f32_split(int dtype, const float* in, void* out, size_t rows, int d, const float* scale_dev, hipStream_t s) {
+  if (rows == 0) return hipSuccess;
+  if (d % 4) return hipErrorInvalidValue;
+  const size_t n4 = rows * (d / 4);
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  if (dtype == DT_F16) hipLaunchKernelGGL(cast_split_kernel<f16>, dim3(grid), dim3(256), 0, s, in, (f16*)out, rows, d / 4, scale_dev);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(cast_split_kernel<bf16>, dim3(grid), dim3(256), 0, s, in, (bf16*)out, rows, d / 4, scale_dev);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 template <typename T>
 __global__ void cast_to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
@@ -263,6 +290,23 @@ hipError_t launch_overwrite_rows(const float* rows, int n, float* x, int B, int 
   return hipGetLastError();
 }
 
+// dst + r*dst_pitch <- src + r*src_pitch, row_bytes each (multiples of 16 B): the CLS-row gathers / scatters of the
+// last image block (one launch instead of a hipMemcpy2DAsync runtime kernel)
+__global__ void copy_rows_strided_kernel(const char* __restrict__ src, char* __restrict__ dst, int rows, size_t src_pitch,
+                                         size_t dst_pitch, int chunks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * chunks) return;
+  const int r = i / chunks, c = i - r * chunks;
+  *(f32x4*)(dst + (size_t)r * dst_pitch + (size_t)c * 16) = *(const f32x4*)(src + (size_t)r * src_pitch + (size_t)c * 16);
+}
+hipError_t launch_copy_rows_strided(const void* src, void* dst, int rows, size_t src_pitch, size_t dst_pitch, int row_bytes, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (row_bytes % 16 || src_pitch % 16 || dst_pitch % 16) return hipErrorInvalidValue;
+  const int chunks = row_bytes / 16, n = rows * chunks;
+  hipLaunchKernelGGL(copy_rows_strided_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const char*)src, (char*)dst, rows, src_pitch, dst_pitch, chunks);
+  return hipGetLastError();
+}
+
 // out[j,:] = inv_scale * sum_b dx32[b, row0+j, :]   (prompt rows are `expand`ed over the batch => sum over B);
 // optionally zero those rows afterwards (deep prompts overwrite the rows: upstream gradient is 0).
 // 16 waves per block: wave w sums images w, w+16, ... (all loads of a wave independent -> one memory latency, not B),
@@ -270,7 +314,7 @@ hipError_t launch_overwrite_rows(const float* rows, int n, float* x, int B, int 
 template <typename T>
 __global__ __launch_bounds__(1024) void reduce_prompt_rows_kernel(float* __restrict__ dx32, T* __restrict__ dx16, int B, int L, int d,
                                                                   int row0, int n, float* __restrict__ out, const float* scale_dev,
-                                                                  int zero_after) {
+                                                                  int zero_after, int split16) {
   __shared__ f32x4 part[16][64];
   const int j = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -284,7 +328,11 @@ __global__ __launch_bounds__(1024) void reduce_prompt_rows_kernel(float* __restr
       acc += *(const f32x4*)(dx32 + o);
       if (zero_after) {
         *(f32x4*)(dx32 + o) = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (dx16) { typename Vec<T>::v4 z; for (int e = 0; e < 4; ++e) z[e] = (T)0.f; *(typename Vec<T>::v4*)(dx16 + o) = z; }
+        if (dx16) {
+          typename Vec<T>::v4 z; for (int e = 0; e < 4; ++e) z[e] = (T)0.f;
+          if (split16) { *(typename Vec<T>::v4*)(dx16 + 2 * (o - c) + c) = z; *(typename Vec<T>::v4*)(dx16 + 2 * (o - c) + d + c) = z; }
+          else *(typename Vec<T>::v4*)(dx16 + o) = z;
+        }
       }
     }
   }
@@ -299,12 +347,12 @@ __global__ __launch_bounds__(1024) void reduce_prompt_rows_kernel(float* __restr
   }
 }
 hipError_t launch_reduce_prompt_rows(int dtype, float* dx32, void* dx16, int B, int L, int d, int row0, int n, float* out,
-                                     const float* scale_dev, int zero_after, hipStream_t s) {
+                                     const float* scale_dev, int zero_after, hipStream_t s, int split16) {
   if (n <= 0) return hipSuccess;
   if (d % 4) return hipErrorInvalidValue;
   dim3 grid((d + 255) / 256, n), block(1024);
-  if (dtype == DT_F16) hipLaunchKernelGGL(reduce_prompt_rows_kernel<f16>, grid, block, 0, s, dx32, (f16*)dx16, B, L, d, row0, n, out, scale_dev, zero_after);
-  else if (dtype == DT_BF16) hipLaunchKernelGGL(reduce_prompt_rows_kernel<bf16>, grid, block, 0, s, dx32, (bf16*)dx16, B, L, d, row0, n, out, scale_dev, zero_after);
+  if (dtype == DT_F16) hipLaunchKernelGGL(reduce_prompt_rows_kernel<f16>, grid, block, 0, s, dx32, (f16*)dx16, B, L, d, row0, n, out, scale_dev, zero_after, split16);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(reduce_prompt_rows_kernel<bf16>, grid, block, 0, s, dx32, (bf16*)dx16, B, L, d, row0, n, out, scale_dev, zero_after, split16);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

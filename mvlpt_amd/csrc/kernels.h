@@ -12,6 +12,10 @@ enum GemmEpi {
   EPI_RESID32 = 2,  // out32 = acc + bias + resid32          (fp32 residual stream, may alias out)
   EPI_GELUBWD = 3,  // out16 = acc * QuickGELU'(aux16)       (aux = saved pre-activation u)
   EPI_STORE32 = 4,  // out32 = acc (+bias)
+  // split-precision outputs: a 16-bit pair (hi = round16(v), lo = round16(v - hi)) stored as ONE row of 2N elements
+  // [hi(0..N) | lo(0..N)], i.e. directly the `a_split` A operand of the next GEMM
+  EPI_GELU_SPLIT = 5,     // u = acc+bias ; out2 (optional, 16-bit [M,N]) = u ; out [M,2N] = split(QuickGELU(u))
+  EPI_GELUBWD_SPLIT = 6,  // out [M,2N] = split(acc * QuickGELU'(aux16))
 };
 struct GemmArgs {
   const void* A;       // [M,K] 16-bit
@@ -22,6 +26,11 @@ struct GemmArgs {
   const float* resid;  // [M,N] fp32   (EPI_RESID32)
   void* out;           // [M,N]
   void* out2;          // [M,N] 16-bit, optional (EPI_GELU)
+  // Split-precision A operand: A is [M, 2K] = [A_hi | A_lo] (16-bit pair, A ~ A_hi + A_lo to ~22 bits) and the
+  // product is A_hi*Bt^T + A_lo*Bt^T in the same fp32 accumulators: the K loop runs over 2K with the Bt K-index wrapping.
+  // The frozen weights are exactly representable in 16 bits (they are stored so, clip/model.py:371-392), so the product
+  // then carries the activations at ~fp32 precision.  Costs twice the MFMA work.
+  int a_split = 0;
 #ifdef MVLPT_GEMM_TRACE
   long long* trace = nullptr;   // debug builds only: per-wave (point id << 56 | s_memtime) records of workgroup 0
 #endif
@@ -42,6 +51,7 @@ struct LnFwdArgs {
   const float* gamma; const float* beta;
   void* y;          // [rows,d] contiguous, 16-bit (out_dtype = compute dtype) or fp32 (out_dtype = DT_F32)
   int rows, d;
+  int split = 0;    // 16-bit outputs only: y is [rows, 2d] = [hi | lo] (split-precision A operand, see GemmArgs::a_split)
 };
 hipError_t launch_ln_fwd(int out_dtype, const LnFwdArgs& a, hipStream_t s);
 
@@ -54,6 +64,7 @@ struct LnBwdArgs {
   float* out32;          // fp32, same row mapping as x (may alias resid)
   void* out16;           // optional 16-bit copy, same row mapping
   int rows, d;
+  int split = 0;         // out16 is [*, 2d] = [hi | lo]
 };
 hipError_t launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s);
 
@@ -80,6 +91,24 @@ hipError_t launch_attn_bwd_cls(int dtype, const void* qkv, const void* o_cls, co
 hipError_t launch_attn_fwd_stream(int dtype, const AttnArgs& a, hipStream_t s);
 hipError_t launch_attn_bwd_stream(int dtype, const AttnBwdArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- fp32 attention (attention32.hip), any L
+// Split-precision mode of the towers that carry a gradient: fp32 Q/K/V in, fp32 arithmetic on the f32 MFMA, outputs as
+// 16-bit hi|lo pairs that are directly the `a_split` A operand of the next GEMM.
+struct Attn32Args {
+  const float* qkv;      // [N*L, 3d] fp32, columns [q | k | v], head h at h*64 inside each third
+  void* out_split;       // [N*L, 2d] 16-bit: [hi(d) | lo(d)]
+  float* lse;            // [N*H*L] or null
+  int N, L, H; int causal;
+  int q_rows = 0;        // > 0: only queries 0..q_rows-1 of every sequence are computed
+};
+hipError_t launch_attn32_fwd(int dtype, const Attn32Args& a, hipStream_t s);
+struct Attn32BwdArgs {
+  const float* qkv; const void* out_split; const float* dout32 /*[N*L,d] fp32*/; const float* lse;
+  float* delta /*[N*H*L] scratch*/; void* dqkv_split /*[N*L, 6d] 16-bit: [hi(3d) | lo(3d)]*/;
+  int N, L, H; int causal;
+};
+hipError_t launch_attn32_bwd(int dtype, const Attn32BwdArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- input pipeline (preprocess.hip)
 // same layout as MvlptImageDesc (include/mvlpt_hip.h)
 struct PpDesc {
@@ -96,6 +125,8 @@ hipError_t launch_preprocess(const uint8_t* src, const PpDesc* descs_dev, int B,
 
 // ---------------------------------------------------------------- glue
 hipError_t launch_cast_f32_to16(int dtype, const float* in, void* out, size_t n, const float* scale_dev, hipStream_t s);
+// fp32 [rows,d] (* scale_dev[0]) -> 16-bit pair [rows, 2d] = [hi | lo]
+hipError_t launch_cast_f32_split(int dtype, const float* in, void* out, size_t rows, int d, const float* scale_dev, hipStream_t s);
 hipError_t launch_cast_any_to_f32(int in_dtype, const void* in, float* out, size_t n, hipStream_t s);
 // W [rows, cols] (fp32) -> out16 [rows, ld_out] zero padded (cols <= ld_out)
 hipError_t launch_pack_weight(int dtype, const float* w, void* out, int rows, int cols, int ld_out, hipStream_t s);
@@ -115,9 +146,11 @@ hipError_t launch_build_ctx_pos(const int32_t* layout, int32_t* ctx_pos, int C, 
 hipError_t launch_eot_rows(const int32_t* eot, int32_t* rows, int C, int L, hipStream_t s);
 // dst[r] = src[idx[r]] (scatter = 0) or dst[idx[r]] = src[r] (scatter = 1); row_bytes % 16 == 0
 hipError_t launch_copy_rows(const void* src, void* dst, const int32_t* idx, int rows, int row_bytes, int scatter, hipStream_t s);
+// rows of row_bytes (multiple of 16) from src + r*src_pitch to dst + r*dst_pitch
+hipError_t launch_copy_rows_strided(const void* src, void* dst, int rows, size_t src_pitch, size_t dst_pitch, int row_bytes, hipStream_t s);
 // out[j,:] = inv_scale * sum_b dx[b, row0+j, :]; optionally zero those rows of dx32/dx16 afterwards
 hipError_t launch_reduce_prompt_rows(int dtype, float* dx32, void* dx16, int B, int L, int d, int row0, int n, float* out,
-                                     const float* scale_dev, int zero_after, hipStream_t s);
+                                     const float* scale_dev, int zero_after, hipStream_t s, int split16 = 0);
 // dctx (generic) [n,d] = inv_scale * sum_c dx[c, ctx_pos[c,j], :]  or (per class) [C,n,d]
 hipError_t launch_gather_ctx_grad(const float* dx, const int32_t* ctx_pos, int C, int L, int d, int n_ctx, int per_class,
                                   float* dctx, const float* scale_dev, hipStream_t s);

@@ -19,6 +19,16 @@ template <> __device__ __forceinline__ void store4<f16>(f16* p, f32x4 v) {
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
   bf16x4 w; for (int e = 0; e < 4; ++e) w[e] = (bf16)v[e]; *(bf16x4*)p = w;
 }
+// split-precision pair: hi = round16(v) at p, lo = round16(v - hi) at p + lo_off
+template <typename TO>
+__device__ __forceinline__ void store4_split(TO* p, int lo_off, f32x4 v) {
+  f32x4 r;
+  store4<TO>(p, v);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = v[e] - (float)(TO)v[e];
+  store4<TO>(p + lo_off, r);
+}
+template <> __device__ __forceinline__ void store4_split<float>(float* p, int, f32x4 v) { *(f32x4*)p = v; }
 template <typename TI>
 __device__ __forceinline__ f32x4 load4(const TI* p);
 template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *(const f32x4*)p; }
@@ -60,7 +70,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
   }
   float mean, rstd;
   row_stats(v, ok, a.d, mean, rstd);
-  TO* y = (TO*)a.y + (size_t)row * a.d;
+  TO* y = (TO*)a.y + (size_t)row * a.d * (a.split ? 2 : 1);
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) if (ok[i]) {
     const int c = (i * 64 + lane) * 4;
@@ -68,7 +78,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-    store4<TO>(y + c, o);
+    if (a.split) store4_split<TO>(y + c, a.d, o); else store4<TO>(y + c, o);
   }
 }
 
@@ -108,13 +118,13 @@ __global__ __launch_bounds__(256) void ln_fwd_stream_kernel(LnFwdArgs a) {
       for (int e = 0; e < 4; ++e) { const float c = cur[i][e] - mean; q += c * c; }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)a.d + LN_EPS);
-    TO* y = (TO*)a.y + (size_t)row * a.d;
+    TO* y = (TO*)a.y + (size_t)row * a.d * (a.split ? 2 : 1);
 #pragma unroll
     for (int i = 0; i < NV; ++i) if (ok[i]) {
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (cur[i][e] - mean) * rstd * g[i][e] + b[i][e];
-      store4<TO>(y + (i * 64 + lane) * 4, o);
+      if (a.split) store4_split<TO>(y + (i * 64 + lane) * 4, a.d, o); else store4<TO>(y + (i * 64 + lane) * 4, o);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
@@ -175,7 +185,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     for (int e = 0; e < 4; ++e) o[e] = rstd * (gg[i][e] - s1 - v[i][e] * s2);
     if (a.resid) o += *(const f32x4*)(a.resid + in_row * a.d + c);
     *(f32x4*)(a.out32 + in_row * a.d + c) = o;
-    if (a.out16) store4<T>((T*)a.out16 + in_row * a.d + c, o);
+    if (a.out16) {
+      if (a.split) store4_split<T>((T*)a.out16 + in_row * a.d * 2 + c, a.d, o);
+      else store4<T>((T*)a.out16 + in_row * a.d + c, o);
+    }
   }
 }
 
@@ -244,7 +257,10 @@ __global__ __launch_bounds__(256) void ln_bwd_stream_kernel(LnBwdArgs a) {
       for (int e = 0; e < 4; ++e) o[e] = rstd * (dc[i][e] - s1 - xc[i][e] * s2);
       if (a.resid) o += rc[i];
       __builtin_nontemporal_store(o, (f32x4*)(a.out32 + in_row * a.d + c));
-      if (a.out16) store4<T>((T*)a.out16 + in_row * a.d + c, o);
+      if (a.out16) {
+        if (a.split) store4_split<T>((T*)a.out16 + in_row * a.d * 2 + c, a.d, o);
+        else store4<T>((T*)a.out16 + in_row * a.d + c, o);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) { xc[i] = xn[i]; dc[i] = dn[i]; rc[i] = rn[i]; }

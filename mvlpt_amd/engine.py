@@ -66,6 +66,7 @@ class Engine:
         with torch.cuda.device(self.device):
             _lib.check(lib.mvlpt_create(C.byref(a), C.byref(h)), None, "mvlpt_create")
         self.h = h
+        self.precision = _lib.PREC_SPLIT_GRAD
         self._keep: List[torch.Tensor] = []     # tensors the library reads asynchronously / later
         self._img_state = None
         self._txt_state = None
@@ -82,6 +83,12 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def set_precision(self, mode) -> None:
+        """"fast" | "split_grad" (default) | "split_all" — see MVLPT_PREC_* in include/mvlpt_hip.h."""
+        code = {"fast": _lib.PREC_FAST, "split_grad": _lib.PREC_SPLIT_GRAD, "split_all": _lib.PREC_SPLIT_ALL}.get(mode, mode)
+        _lib.check(lib.mvlpt_set_precision(self.h, int(code)), self.h, "set_precision")
+        self.precision = int(code)
 
     @classmethod
     def from_state_dict(cls, sd: Dict[str, torch.Tensor], compute_dtype: str = "fp16", device=None,
@@ -250,7 +257,8 @@ class Engine:
         n = lib.mvlpt_profile_end(self.h, arr, 16)
         if n < 0:
             raise RuntimeError("profile_end failed")
-        return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes, busy_ms=arr[i].busy_ms)
+        return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes,
+                                           busy_ms=arr[i].busy_ms, flops_executed=arr[i].flops_executed)
                 for i in range(n)}
 
 
@@ -265,6 +273,68 @@ def op_gemm(A, Bt, epi=_lib.EPI_STORE16, bias=None, aux=None, resid=None, out2=F
     _lib.check(lib.mvlpt_op_gemm(dt, epi, _ptr(A.contiguous()), _ptr(Bt.contiguous()), M, N, K, _ptr(bias), _ptr(aux),
                                  _ptr(resid), _ptr(out), _ptr(o2), _stream()), None, "op_gemm")
     return (out, o2) if out2 else out
+
+
+def split_pair(x: torch.Tensor, dtype) -> torch.Tensor:
+    """fp32 [M,K] -> 16-bit hi|lo pair [M,2K] (the layout of GemmArgs::a_split; host-side helper for tests)."""
+    hi = x.to(dtype)
+    lo = (x - hi.float()).to(dtype)
+    return torch.cat([hi, lo], dim=1).contiguous()
+
+
+def join_pair(p: torch.Tensor) -> torch.Tensor:
+    k = p.shape[1] // 2
+    return p[:, :k].float() + p[:, k:].float()
+
+
+def op_gemm_split(A2, Bt, epi=_lib.EPI_STORE32, bias=None, aux=None, resid=None, out2=False):
+    """A2: 16-bit pair [M,2K]."""
+    dt = _TORCH2DT[A2.dtype]
+    M, K = A2.shape[0], A2.shape[1] // 2
+    N = Bt.shape[0]
+    if epi in (_lib.EPI_RESID32, _lib.EPI_STORE32):
+        out = torch.empty(M, N, device=A2.device, dtype=torch.float32)
+    elif epi in (_lib.EPI_GELU_SPLIT, _lib.EPI_GELUBWD_SPLIT):
+        out = torch.empty(M, 2 * N, device=A2.device, dtype=A2.dtype)
+    else:
+        out = torch.empty(M, N, device=A2.device, dtype=A2.dtype)
+    o2 = torch.empty(M, N, device=A2.device, dtype=A2.dtype) if out2 else None
+    _lib.check(lib.mvlpt_op_gemm_split(dt, epi, _ptr(A2.contiguous()), _ptr(Bt.contiguous()), M, N, K, _ptr(bias), _ptr(aux),
+                                       _ptr(resid), _ptr(out), _ptr(o2), _stream()), None, "op_gemm_split")
+    return (out, o2) if out2 else out
+
+
+def op_layernorm_fwd_split(x, gamma, beta, out_dtype):
+    rows, d = x.shape
+    y = torch.empty(rows, 2 * d, device=x.device, dtype=out_dtype)
+    _lib.check(lib.mvlpt_op_layernorm_fwd_split(_TORCH2DT[out_dtype], _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), rows, d, _stream()),
+               None, "op_layernorm_fwd_split")
+    return y
+
+
+def op_layernorm_bwd_split(dy32, x, gamma, dtype, resid=None):
+    rows, d = x.shape
+    out32 = torch.empty(rows, d, device=x.device, dtype=torch.float32)
+    out16 = torch.empty(rows, 2 * d, device=x.device, dtype=dtype)
+    _lib.check(lib.mvlpt_op_layernorm_bwd_split(_TORCH2DT[dtype], _ptr(dy32), _ptr(x), _ptr(gamma), _ptr(resid), _ptr(out32),
+                                                _ptr(out16), rows, d, _stream()), None, "op_layernorm_bwd_split")
+    return out32, out16
+
+
+def op_attention32_fwd(qkv32, N, L, H, causal, dtype=torch.float16, q_rows=0):
+    out = torch.zeros(N * L, 2 * H * 64, device=qkv32.device, dtype=dtype)
+    lse = torch.zeros(N * H * L, device=qkv32.device, dtype=torch.float32)
+    _lib.check(lib.mvlpt_op_attention32_fwd(_TORCH2DT[dtype], _ptr(qkv32), _ptr(out), _ptr(lse), N, L, H, int(causal), q_rows,
+                                            _stream()), None, "op_attention32_fwd")
+    return out, lse
+
+
+def op_attention32_bwd(qkv32, out_pair, dout32, lse, N, L, H, causal):
+    dqkv = torch.empty(N * L, 6 * H * 64, device=qkv32.device, dtype=out_pair.dtype)
+    delta = torch.empty(N * H * L, device=qkv32.device, dtype=torch.float32)
+    _lib.check(lib.mvlpt_op_attention32_bwd(_TORCH2DT[out_pair.dtype], _ptr(qkv32), _ptr(out_pair), _ptr(dout32), _ptr(lse),
+                                            _ptr(delta), _ptr(dqkv), N, L, H, int(causal), _stream()), None, "op_attention32_bwd")
+    return dqkv
 
 
 def op_layernorm_fwd(x, gamma, beta, out_dtype):

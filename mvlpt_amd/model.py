@@ -100,9 +100,10 @@ class FrozenCLIP:
     HIP engine; this object only carries what the prompt learner needs at construction time."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], compute_dtype: str = "fp16", device=None,
-                 tokenizer=None, arch: Optional[ClipArch] = None, token_seed: int = 0):
+                 tokenizer=None, arch: Optional[ClipArch] = None, token_seed: int = 0, precision: str = "split_grad"):
         self.arch = arch or arch_from_state_dict(state_dict)
         self.engine = Engine.from_state_dict(state_dict, compute_dtype, device, self.arch)
+        self.engine.set_precision(precision)       # "fast" | "split_grad" | "split_all" (include/mvlpt_hip.h MVLPT_PREC_*)
         self.device = self.engine.device
         self.context_length = self.arch.context_length
         self.logit_scale = state_dict["logit_scale"].detach().float().to(self.device)     # frozen, clip/model.py:291

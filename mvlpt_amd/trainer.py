@@ -313,7 +313,10 @@ class MVLPT(TrainerX):
         if sd is None:
             # no network: synthetic frozen weights of the named architecture (clip/clip.py:57 would download)
             sd = make_state_dict(ARCHS[cfg.MODEL.BACKBONE.NAME], seed=cfg.SEED)
-        clip_model = FrozenCLIP(sd, compute_dtype=cfg.TRAINER.MVLPT.COMPUTE_DTYPE, device=self.device)
+        # PREC (see check_cfg): fp16 / amp -> split operands only where gradients flow; fp32 -> in every tower;
+        # GRAD_PRECISION = "fast" (not in the reference) drops the split operands altogether (gradients within ~4e-3)
+        prec = "split_all" if cfg.TRAINER.MVLPT.PREC == "fp32" else cfg.TRAINER.MVLPT.GRAD_PRECISION
+        clip_model = FrozenCLIP(sd, compute_dtype=cfg.TRAINER.MVLPT.COMPUTE_DTYPE, device=self.device, precision=prec)
         self.model = CustomCLIP(cfg, classnames, clip_model, dm=self.dm)
         for name, param in self.model.named_parameters():               # :855-858 (the towers hold no nn.Parameters)
             if "prompt_learner" not in name:

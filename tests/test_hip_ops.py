@@ -165,3 +165,111 @@ def test_gemm_race_screen(M, N, K, epi):
             assert relerr(out, ref) < (2e-5 if epi == 2 else 2e-3)
         else:
             assert torch.equal(out, first), f"run {it} differs from run 0 (race)"
+
+
+# ---------------------------------------------------------------------------------------------- split-precision mode
+# (hi+lo 16-bit operand pairs for the GEMM A operand, fp32 attention: DESIGN.md "Precision modes").  The weights are
+# exactly 16-bit (as CLIP checkpoints are); the activations are arbitrary fp32: the results must match an fp32 matmul to
+# ~2^-21 relative, i.e. three orders of magnitude better than the single-operand kernels above.
+SPLIT_TOL = {torch.float16: 3e-6, torch.bfloat16: 6e-5}    # pair = 22 / 16 significant bits
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (391, 512, 256), (77, 128, 128), (1000, 768, 3072), (4096, 2304, 768), (30000, 768, 768)])
+def test_gemm_split_operand(dtype, M, N, K):
+    E = _eng()
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    A = torch.randn(M, K, generator=g)                                   # fp32 activations, NOT pre-rounded
+    Bt = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double() @ Bt.double().t() + bias.double()).float()
+    A2 = E.split_pair(A, dtype).cuda()
+    assert relerr(E.join_pair(A2), A) < SPLIT_TOL[dtype] * 0.5
+    out = E.op_gemm_split(A2, Bt.cuda(), E._lib.EPI_STORE32, bias=bias.cuda())
+    assert relerr(out, ref) < SPLIT_TOL[dtype]
+    resid = torch.randn(M, N, generator=g)
+    outr = E.op_gemm_split(A2, Bt.cuda(), E._lib.EPI_RESID32, bias=bias.cuda(), resid=resid.cuda())
+    assert relerr(outr, ref + resid) < SPLIT_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_split_epilogues(dtype):
+    E = _eng()
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 391, 512, 256
+    A = torch.randn(M, K, generator=g)
+    Bt = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype)
+    bias = torch.randn(N, generator=g)
+    acc = (A.double() @ Bt.double().t()).float()
+    A2 = E.split_pair(A, dtype).cuda()
+    a_pair, u16 = E.op_gemm_split(A2, Bt.cuda(), E._lib.EPI_GELU_SPLIT, bias=bias.cuda(), out2=True)
+    assert a_pair.shape == (M, 2 * N)
+    # the device's QuickGELU uses v_exp/v_rcp (~1 ulp each): fp32-level agreement, not pair-level
+    assert relerr(E.join_pair(a_pair), O.quick_gelu(acc + bias)) < 2e-6 * (1 if dtype == torch.float16 else 40)
+    assert relerr(u16, acc + bias) < TOL[dtype]
+    u = torch.randn(M, N, generator=g).to(dtype)
+    d_pair = E.op_gemm_split(A2, Bt.cuda(), E._lib.EPI_GELUBWD_SPLIT, aux=u.cuda())
+    assert relerr(E.join_pair(d_pair), acc * O.quick_gelu_grad(u.float())) < 2e-6 * (1 if dtype == torch.float16 else 40)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d,rows", [(128, 203), (512, 4099), (768, 20011), (1024, 300)])
+def test_layernorm_split_outputs(dtype, d, rows):
+    E = _eng()
+    g = torch.Generator().manual_seed(d + 1)
+    x = torch.randn(rows, d, generator=g) * 3 + 0.5
+    gamma = 1 + 0.1 * torch.randn(d, generator=g)
+    beta = 0.1 * torch.randn(d, generator=g)
+    y_ref, (xhat, rstd) = O.layernorm_fwd(x, gamma, beta)
+    y2 = E.op_layernorm_fwd_split(x.cuda(), gamma.cuda(), beta.cuda(), dtype)
+    assert y2.shape == (rows, 2 * d) and relerr(E.join_pair(y2), y_ref) < max(2e-6, SPLIT_TOL[dtype])
+    dy = torch.randn(rows, d, generator=g)
+    resid = torch.randn(rows, d, generator=g)
+    dx_ref = resid + O.layernorm_bwd(dy, xhat, rstd, gamma)
+    dx32, dx2 = E.op_layernorm_bwd_split(dy.cuda(), x.cuda(), gamma.cuda(), dtype, resid.cuda())
+    assert relerr(dx32, dx_ref) < 2e-5
+    assert relerr(E.join_pair(dx2), dx32) < SPLIT_TOL[dtype]          # the pair carries the fp32 result
+
+
+@pytest.mark.parametrize("L,causal", [(5, False), (5, True), (24, True), (64, True), (65, False), (77, True), (197, False), (205, False),
+                                      (261, False), (581, False)])
+def test_attention32_fwd_bwd(L, causal):
+    """fp32 attention core of the split-precision mode: fp32 in, f32 MFMA, pair outputs — fp32-level agreement with the oracle."""
+    E = _eng()
+    N, H = 3, 2
+    d = H * 64
+    g = torch.Generator().manual_seed(L * 2 + int(causal) + 100)
+    qkv = torch.randn(N * L, 3 * d, generator=g)
+    q, k, v, o, p = _attn_ref(qkv, N, L, H, causal)
+    out2, lse = E.op_attention32_fwd(qkv.cuda(), N, L, H, causal)
+    o_ref = o.permute(0, 2, 1, 3).reshape(N * L, d)
+    assert relerr(E.join_pair(out2), o_ref) < 5e-6
+    s = torch.matmul(q, k.transpose(-1, -2)) / 8.0
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu_(1)
+    assert float((lse.cpu() - torch.logsumexp(s, -1).reshape(-1)).abs().max()) < 1e-5
+    dout = torch.randn(N * L, d, generator=g)
+    do = dout.reshape(N, L, H, 64).permute(0, 2, 1, 3)
+    dq, dk, dv = O.attention_bwd(do, q, k, v, p)
+    dqkv_ref = torch.cat([t.permute(0, 2, 1, 3).reshape(N * L, d) for t in (dq, dk, dv)], dim=-1)
+    dqkv = E.join_pair(E.op_attention32_bwd(qkv.cuda(), out2, dout.cuda(), lse, N, L, H, causal))
+    for i, nm in enumerate("qkv"):
+        e = relerr(dqkv[:, i * d:(i + 1) * d], dqkv_ref[:, i * d:(i + 1) * d])
+        assert e < 1e-5, f"d{nm}: {e}"
+    # CLS-only forward (last image block): only query 0 of every sequence is produced, the rest stays untouched
+    if not causal:
+        o1, _ = E.op_attention32_fwd(qkv.cuda(), N, L, H, causal, q_rows=1)
+        got = E.join_pair(o1).cpu().reshape(N, L, d)
+        assert relerr(got[:, 0], o_ref.reshape(N, L, d)[:, 0]) < 5e-6 and float(got[:, 1:].abs().max()) == 0.0
+
+
+def test_attention32_is_not_transposed():
+    E = _eng()
+    N, L, H = 1, 40, 1
+    qkv = torch.zeros(L, 192)
+    qkv[:, 128:] = torch.arange(L).float().view(L, 1) * 0.01 + torch.arange(64).float().view(1, 64) * 1e-3
+    qkv[7, 0] = 8.0
+    qkv[23, 64] = 8.0
+    out2, _ = E.op_attention32_fwd(qkv.cuda(), N, L, H, False)
+    _, _, _, o, _ = _attn_ref(qkv, N, L, H, False)
+    assert relerr(E.join_pair(out2), o.reshape(L, 64)) < 5e-6
