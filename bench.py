@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--no-step-pipelining", action="store_true",
                     help="do not compute the next batch's image features underneath the current backward")
     ap.add_argument("--shard-text", action="store_true", help="class-shard the text tower over the ranks (many-class configs)")
+    ap.add_argument("--grad-precision", default="split_grad", choices=["split_grad", "fast"],
+                    help="split_grad (default): hi+lo operand pairs + fp32 attention in towers that carry a gradient (prompt "
+                         "gradients within 1e-3 of the fp32 CPU path); fast: single 16-bit operands everywhere (~4e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--all-kernel-timing", action="store_true", help="bracket every kernel class with marker events (slower)")
@@ -124,6 +127,7 @@ def main():
     cfg.INPUT.SIZE = (arch.image_resolution, arch.image_resolution)
     cfg.DATALOADER.TRAIN_X.BATCH_SIZE = args.batch
     cfg.TRAINER.MVLPT.COMPUTE_DTYPE = args.dtype
+    cfg.TRAINER.MVLPT.GRAD_PRECISION = args.grad_precision
     cfg.TRAINER.CUT_CONTEXTLEN = args.cut
     n_ctx = n_vpt = 0
     if args.method in ("coop", "upt"):
@@ -227,6 +231,7 @@ def main():
                                     f"n_ctx={n_ctx} n_vpt={n_vpt}, text L={L_text}, class token middle"),
                        "text_positions_evaluated": (trainer.model.prompt_learner.max_eot + 1) if args.trim_eot else L_text,
                        "step_pipelining": bool(pipeline and n_vpt == 0),
+                       "grad_precision": args.grad_precision,
                        "per_gpu_batch": args.batch, "global_batch": B_global, "parallelism": f"dp{world}",
                        "text_tower": "class-sharded over ranks" if (args.shard_text and world > 1) else "replicated per GPU", "loss": round(loss, 5)},
             "step_mfma_fraction": round(ips / world * gf_img / (MFMA_PEAK_TFLOPS * 1e3), 4),

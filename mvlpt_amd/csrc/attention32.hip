@@ -69,7 +69,7 @@ template <typename T>
 __device__ __forceinline__ void store_pair4(T* p, size_t lo_off, f32x4 v) {
   typename Vec<T>::v4 hi, lo;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { hi[e] = from_f32<T>(v[e]); lo[e] = from_f32<T>(v[e] - to_f32<T>(hi[e])); }
+  for (int e = 0; e < 4; ++e) { T h, l; split16<T>(v[e], h, l); hi[e] = h; lo[e] = l; }
   *(typename Vec<T>::v4*)p = hi;
   *(typename Vec<T>::v4*)(p + lo_off) = lo;
 }

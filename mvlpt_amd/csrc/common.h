@@ -35,6 +35,17 @@ __device__ __forceinline__ f32x4 mfma16<bf16>(bf16x8 a, bf16x8 b, f32x4 c) {
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return static_cast<float>(v); }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return static_cast<T>(v); }
 
+// Split-precision pair of a fp32 value: hi = round16(v), lo = round16(v - hi); hi + lo carries ~22 (fp16) / 16 (bf16) bits.
+// `v` is materialised first: with fp-contract the compiler otherwise folds a producing multiply into v_fma_mix* for ONE of
+// the two uses of hi (single rounding of the exact product) while the stored hi is converted from the rounded fp32 value
+// (double rounding) — near a rounding tie the two differ by one 16-bit ulp and the pair is off by that ulp.
+template <typename T>
+__device__ __forceinline__ void split16(float v, T& hi, T& lo) {
+  asm volatile("" : "+v"(v));
+  hi = from_f32<T>(v);
+  lo = from_f32<T>(v - to_f32<T>(hi));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -156,8 +156,9 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
             float r;
             if constexpr (EPI == EPI_GELU_SPLIT) { r = quick_gelu(v[e]); u16[e] = from_f32<T>(v[e]); }
             else r = v[e] * quick_gelu_grad(to_f32<T>(uv[i][it][e]));
-            hi[e] = from_f32<T>(r);
-            lo[e] = from_f32<T>(r - to_f32<T>(hi[e]));
+            T h, l;
+            split16<T>(r, h, l);
+            hi[e] = h; lo[e] = l;
           }
           if (m < M) {
             T* row = (T*)g.out + (size_t)m * (2 * N) + nbase + c * 4;

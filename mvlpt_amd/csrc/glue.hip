@@ -41,7 +41,7 @@ __global__ void cast_split_kernel(const float* __restrict__ in, T* __restrict__ 
     const f32x4 v = *(const f32x4*)(in + i * 4) * sc;
     typename Vec<T>::v4 hi, lo;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { hi[e] = (T)v[e]; lo[e] = (T)(v[e] - (float)hi[e]); }
+    for (int e = 0; e < 4; ++e) { T h, l; split16<T>(v[e], h, l); hi[e] = h; lo[e] = l; }
     T* row = out + r * (size_t)(8 * d4);
     *(typename Vec<T>::v4*)(row + c) = hi;
     *(typename Vec<T>::v4*)(row + 4 * d4 + c) = lo;

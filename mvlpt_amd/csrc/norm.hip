@@ -22,11 +22,11 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
 // split-precision pair: hi = round16(v) at p, lo = round16(v - hi) at p + lo_off
 template <typename TO>
 __device__ __forceinline__ void store4_split(TO* p, int lo_off, f32x4 v) {
-  f32x4 r;
-  store4<TO>(p, v);
+  typename Vec<TO>::v4 hi, lo;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) r[e] = v[e] - (float)(TO)v[e];
-  store4<TO>(p + lo_off, r);
+  for (int e = 0; e < 4; ++e) { TO h, l; split16<TO>(v[e], h, l); hi[e] = h; lo[e] = l; }
+  *(typename Vec<TO>::v4*)p = hi;
+  *(typename Vec<TO>::v4*)(p + lo_off) = lo;
 }
 template <> __device__ __forceinline__ void store4_split<float>(float* p, int, f32x4 v) { *(f32x4*)p = v; }
 template <typename TI>

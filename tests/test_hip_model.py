@@ -2,13 +2,15 @@
 (`CustomCLIP(image, task)` -> logits, cross-entropy, `.backward()` into `prompt_learner` parameters) against the
 golden vectors produced by the REAL reference on its CPU fp32 path (oracle/make_golden.py).
 
-Tolerances (BASELINE.json north_star: "logits/grads within 1e-3 fp16 rel-tol", "logits within 1e-3 of CPU
-reference"), fp16 MFMA inputs / fp32 accumulation, integer tables bit-exact:
-  logits   : max|a-b| <= 1e-3 * max(1, max|ref|)      (allclose-style rtol = atol = 1e-3 in the max norm)
+Tolerances = BASELINE.json north_star ("logits/grads within 1e-3 fp16 rel-tol", "logits within 1e-3 of CPU reference"),
+default engine mode (fp16 MFMA inputs, fp32 accumulation; towers that carry a gradient run with split hi+lo operands and
+fp32 attention — MVLPT_PREC_SPLIT_GRAD), integer tables bit-exact:
+  logits   : max|a-b| <= 1e-3 * max(1, max|ref|)  AND  element-wise allclose(rtol = atol = 1e-3)
   features : max|a-b| <= 1e-3 * max|ref|              (tower outputs before the head)
   loss     : |a-b|    <= 1e-3
-  prompt gradients: max|a-b| <= GRAD_TOL * max|ref| with GRAD_TOL = 5e-3.  Measured 0.7e-3 .. 3.7e-3: the 1e-3 goal
-  is NOT met for every gradient tensor yet (each 16-bit MFMA operand rounding adds ~3e-4)."""
+  prompt gradients (every tensor): max|a-b| <= 1e-3 * max|ref|  AND  element-wise |a-b| <= 1e-3 * (max|ref| + |ref|)
+Secondary, labelled modes: bf16 MFMA inputs (3 fewer mantissa bits) and MVLPT_PREC_FAST (single 16-bit operands in every
+tower: measured 1.2e-3 .. 4.1e-3 on the gradients) keep their own, looser bounds."""
 import numpy as np
 import pytest
 import torch
@@ -17,13 +19,12 @@ from tests.golden_util import TINY_CASES, case_grads, case_params, load_npz, t, 
 
 pytestmark = pytest.mark.gpu
 
-TOL_FP16 = 1e-3
-# the width-128 toy towers have 6x fewer terms per dot product than ViT-B (768), so the same per-element 16-bit
-# operand rounding averages out less: measured 0.4e-3 .. 2.2e-3 on the tiny cases, <= 0.8e-3 on ViT-B/32, ViT-B/16
-TOL_TINY_FP16 = 2.5e-3
-GRAD_TOL_FP16 = 5e-3
+TOL_FP16 = 1e-3          # north_star
+TOL_TINY_FP16 = 1e-3
+GRAD_TOL_FP16 = 1e-3
 TOL_BF16 = 2.5e-2     # bf16 has 3 fewer mantissa bits; kept as a secondary mode only
 GRAD_TOL_BF16 = 6e-2
+TOL_FAST, GRAD_TOL_FAST = 2.5e-3, 5e-3    # MVLPT_PREC_FAST (secondary mode: single 16-bit operands everywhere)
 
 
 def cfg_for_case(case, image_size):
@@ -87,6 +88,7 @@ def run_case(case, model, image, tol, gtol):
     ref = t(case["out_logits"])
     err = float((logits.detach().cpu() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
     assert err < tol, f"logits err {err:.3e} (relative to max(1, max|ref|))"
+    assert torch.allclose(logits.detach().cpu(), ref, rtol=tol, atol=tol), "logits: element-wise allclose failed"
     assert abs(float(loss.detach()) - float(case["out_loss"])) < tol
     G = case_grads(case)
     got = {n: p.grad for n, p in model.prompt_learner.named_parameters()}
@@ -96,6 +98,8 @@ def run_case(case, model, image, tol, gtol):
         assert got[k] is not None, f"no gradient for {k}"
         e = float((got[k].cpu() - g).abs().max()) / (float(g.abs().max()) + 1e-20)
         worst[k] = e
+        # element-wise: no entry may be off by more than gtol of (the tensor's scale + its own magnitude)
+        assert bool(((got[k].cpu() - g).abs() <= gtol * (g.abs().max() + g.abs())).all()), f"{k}: element-wise bound failed"
     bad = {k: v for k, v in worst.items() if v >= gtol}
     assert not bad, f"prompt-gradient rel-to-max errors over {gtol:g}: {bad}"
     return err, worst
@@ -119,6 +123,20 @@ def test_tiny_case_fp16(name, tiny_clip_fp16):
     model = build_model(case, tiny_clip_fp16, 32, t(case["token_prefix"]), t(case["token_suffix"]))
     err, worst = run_case(case, model, t(case["image"]), TOL_TINY_FP16, GRAD_TOL_FP16)
     print(f"{name}: logits {err:.2e} grads {max(worst.values()):.2e}")
+
+
+@pytest.fixture(scope="module")
+def tiny_clip_fast():
+    from mvlpt_amd.model import FrozenCLIP
+    return FrozenCLIP(tiny_state_dict(), compute_dtype="fp16", precision="fast")
+
+
+@pytest.mark.parametrize("name", ["tiny_coop_middle", "tiny_vpt_deep", "tiny_upt", "tiny_soft_labels"])
+def test_tiny_case_fast_mode(name, tiny_clip_fast):
+    """MVLPT_PREC_FAST (secondary mode, GRAD_PRECISION = "fast"): the single-operand kernels stay covered end to end."""
+    case = load_npz(name)
+    model = build_model(case, tiny_clip_fast, 32, t(case["token_prefix"]), t(case["token_suffix"]))
+    run_case(case, model, t(case["image"]), TOL_FAST, GRAD_TOL_FAST)
 
 
 @pytest.mark.parametrize("name", ["tiny_coop_middle", "tiny_vpt_deep", "tiny_upt"])
