@@ -259,8 +259,204 @@ __global__ __launch_bounds__(256) void attn32_dkv_kernel(Attn32BwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ short sequences
+// L <= 80 (every text sequence: context_length 77; the tiny test towers): ONE workgroup of 5 waves per (sequence, head),
+// wave t owns the 16-row tile t; all of K, V (forward) or Q, K, V, dO (backward) are staged in LDS once, so the whole
+// head costs two barriers instead of a staged chunk per 64 rows per pass, and the backward runs dQ and dK/dV in one
+// launch (100 classes x 8 heads x 12 layers of L = 77: 151 -> ~30 us per layer for the backward).
+namespace {
+constexpr int SNT = 5, SROWS = SNT * 16;           // tiles / padded rows
+
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, size_t ld, int L, int tid, int nthreads) {
+  for (int idx = tid; idx < SROWS * 16; idx += nthreads) {
+    const int r = idx >> 4, c = (idx & 15) * 4;
+    const int row = r < L ? r : L - 1;
+    *(f32x4*)(dst + r * RS + c) = *(const f32x4*)(src + (size_t)row * ld + c);
+  }
+}
+// one 16-row tile of the streamed side: lane holds [own = fr][streamed = 16*kt + 4fg + r]
+__device__ __forceinline__ f32x4 mm_tile(const float* lds, int kt, const f32x4 (&own)[4], int fr, int fg) {
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f32x4 c = *(const f32x4*)(lds + (16 * kt + fr) * RS + 16 * t + 4 * fg);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a = mfma32(c[s], own[t][s], a);
+  }
+  return a;
+}
+__device__ __forceinline__ void accum_tile(f32x4 (&out)[4], const float* lds, int kt, const f32x4& p, int fr, int fg) {
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[dt] = mfma32(lds[(16 * kt + 4 * fg + r) * RS + 16 * dt + fr], p[r], out[dt]);
+}
+}  // namespace
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(SNT * 64) void attn32s_fwd_kernel(Attn32Args a) {
+  __shared__ __attribute__((aligned(16))) float Ks[SROWS * RS];
+  __shared__ __attribute__((aligned(16))) float Vs[SROWS * RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int n = blockIdx.y, h = blockIdx.x, L = a.L, d = a.H * 64;
+  const size_t ld = 3 * (size_t)d;
+  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
+  stage_rows(Ks, base + d, ld, L, tid, SNT * 64);
+  stage_rows(Vs, base + 2 * d, ld, L, tid, SNT * 64);
+  const int nt = (L + 15) >> 4;
+  const int qlim = a.q_rows > 0 ? (a.q_rows < L ? a.q_rows : L) : L;
+  const int q = wave * 16 + fr, qc = q < L ? q : L - 1;
+  f32x4 Q[4];
+  load_own(Q, base + (size_t)qc * ld, fg);
+  __syncthreads();
+  if (wave * 16 >= qlim) return;
+  const int kt_end = CAUSAL ? wave + 1 : nt;
+  f32x4 S[SNT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < SNT; ++kt) {
+    if (kt < kt_end) {
+      S[kt] = mm_tile(Ks, kt, Q, fr, fg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = 16 * kt + 4 * fg + r;
+        const bool ok = kk < L && (!CAUSAL || kk <= q);
+        S[kt][r] = ok ? S[kt][r] * SCALE : -INFINITY;
+        mx = fmaxf(mx, S[kt][r]);
+      }
+    }
+  }
+  mx = quad_max32(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < SNT; ++kt)
+    if (kt < kt_end) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { S[kt][r] = expf(S[kt][r] - mx); sum += S[kt][r]; }
+    }
+  sum = quad_sum32(sum);
+  f32x4 O[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < SNT; ++kt)
+    if (kt < kt_end) accum_tile(O, Vs, kt, S[kt], fr, fg);
+  if (q < qlim) {
+    const float inv = 1.f / sum;
+    T* orow = (T*)a.out_split + ((size_t)n * L + q) * (2 * (size_t)d) + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, d, O[dt] * inv);
+    if (a.lse && fg == 0) a.lse[((size_t)n * a.H + h) * L + q] = mx + logf(sum);
+  }
+}
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(SNT * 64) void attn32s_bwd_kernel(Attn32BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem32[];
+  float* Qs = smem32;
+  float* Ks = Qs + SROWS * RS;
+  float* Vs = Ks + SROWS * RS;
+  float* Gs = Vs + SROWS * RS;                    // dO
+  float* lse_s = Gs + SROWS * RS;
+  float* del_s = lse_s + SROWS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int n = blockIdx.y, h = blockIdx.x, L = a.L, d = a.H * 64;
+  const size_t ld = 3 * (size_t)d;
+  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
+  stage_rows(Qs, base, ld, L, tid, SNT * 64);
+  stage_rows(Ks, base + d, ld, L, tid, SNT * 64);
+  stage_rows(Vs, base + 2 * d, ld, L, tid, SNT * 64);
+  stage_rows(Gs, a.dout32 + (size_t)n * L * d + h * 64, d, L, tid, SNT * 64);
+  const size_t stat0 = ((size_t)n * a.H + h) * L;
+  const int nt = (L + 15) >> 4;
+  const int row = wave * 16 + fr, rc = row < L ? row : L - 1;     // own row: query in phase A, key in phase B
+  // delta = rowsum(dO * O) of the own query row, from global (dO fp32, O as a pair)
+  float dl = 0.f;
+  {
+    const T* orow = (const T*)a.out_split + ((size_t)n * L + rc) * (2 * (size_t)d) + h * 64;
+    const float* grow = a.dout32 + ((size_t)n * L + rc) * d + h * 64;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 o = load_pair4<T>(orow + 16 * t + 4 * fg, d);
+      const f32x4 g = *(const f32x4*)(grow + 16 * t + 4 * fg);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dl += o[e] * g[e];
+    }
+    dl = quad_sum32(dl);
+  }
+  const float lse = a.lse[stat0 + rc];
+  if (fg == 0) { lse_s[row] = lse; del_s[row] = dl; }
+  __syncthreads();
+  if (wave >= nt) return;
+  T* orow = (T*)a.dqkv_split + ((size_t)n * L + rc) * (6 * (size_t)d) + h * 64;
+  // ---- phase A: own query tile -> dQ
+  {
+    f32x4 Q[4], dO[4], dQ[4];
+    load_own(Q, Qs + row * RS, fg);
+    load_own(dO, Gs + row * RS, fg);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dQ[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kt_end = CAUSAL ? wave + 1 : nt;
+#pragma unroll
+    for (int kt = 0; kt < SNT; ++kt)
+      if (kt < kt_end) {
+        f32x4 S = mm_tile(Ks, kt, Q, fr, fg);
+        const f32x4 dP = mm_tile(Vs, kt, dO, fr, fg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = 16 * kt + 4 * fg + r;
+          const bool ok = kk < L && (!CAUSAL || kk <= row);
+          const float p = ok ? expf(S[r] * SCALE - lse) : 0.f;
+          S[r] = p * (dP[r] - dl);
+        }
+        accum_tile(dQ, Ks, kt, S, fr, fg);
+      }
+    if (row < L) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, 3 * (size_t)d, dQ[dt] * SCALE);
+    }
+  }
+  // ---- phase B: own key tile -> dK, dV
+  {
+    f32x4 K[4], V[4], dK[4], dV[4];
+    load_own(K, Ks + row * RS, fg);
+    load_own(V, Vs + row * RS, fg);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dK[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int qt = 0; qt < SNT; ++qt)
+      if (qt < nt && (!CAUSAL || qt >= wave)) {
+        f32x4 S = mm_tile(Qs, qt, K, fr, fg);            // lane: [key = fr][query = 16qt + 4fg + r]
+        f32x4 dP = mm_tile(Gs, qt, V, fr, fg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq = 16 * qt + 4 * fg + r;
+          const bool ok = qq < L && row < L && (!CAUSAL || row <= qq);
+          const float p = ok ? expf(S[r] * SCALE - lse_s[qq]) : 0.f;
+          S[r] = p;
+          dP[r] = p * (dP[r] - del_s[qq]);
+        }
+        accum_tile(dV, Gs, qt, S, fr, fg);
+        accum_tile(dK, Qs, qt, dP, fr, fg);
+      }
+    if (row < L) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        store_pair4<T>(orow + d + 16 * dt + 4 * fg, 3 * (size_t)d, dK[dt] * SCALE);
+        store_pair4<T>(orow + 2 * d + 16 * dt + 4 * fg, 3 * (size_t)d, dV[dt]);
+      }
+    }
+  }
+}
+
 template <typename T>
 static hipError_t fwd_t(const Attn32Args& a, hipStream_t s) {
+  if (a.L <= SROWS) {
+    dim3 grid(a.H, a.N), block(SNT * 64);
+    if (a.causal) hipLaunchKernelGGL((attn32s_fwd_kernel<T, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn32s_fwd_kernel<T, false>), grid, block, 0, s, a);
+    return hipGetLastError();
+  }
   const int lq = a.q_rows > 0 ? (a.q_rows < a.L ? a.q_rows : a.L) : a.L;
   dim3 grid((lq + CH - 1) / CH, a.H, a.N), block(256);
   if (a.causal) hipLaunchKernelGGL((attn32_fwd_kernel<T, true>), grid, block, 0, s, a);
@@ -269,6 +465,19 @@ static hipError_t fwd_t(const Attn32Args& a, hipStream_t s) {
 }
 template <typename T>
 static hipError_t bwd_t(const Attn32BwdArgs& a, hipStream_t s) {
+  if (a.L <= SROWS) {
+    constexpr int LDS = (4 * SROWS * RS + 2 * SROWS) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)attn32s_bwd_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)attn32s_bwd_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      attr_set = true;
+    }
+    dim3 grid(a.H, a.N), block(SNT * 64);
+    if (a.causal) hipLaunchKernelGGL((attn32s_bwd_kernel<T, true>), grid, block, LDS, s, a);
+    else hipLaunchKernelGGL((attn32s_bwd_kernel<T, false>), grid, block, LDS, s, a);
+    return hipGetLastError();
+  }
   dim3 grid((a.L + CH - 1) / CH, a.H, a.N), block(256);
   if (a.causal) {
     hipLaunchKernelGGL((attn32_dq_kernel<T, true>), grid, block, 0, s, a);

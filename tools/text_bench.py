@@ -5,7 +5,7 @@ import torch
 from mvlpt_amd.model import FrozenCLIP, build_prompt_layout
 from mvlpt_amd.weights import ARCHS, make_state_dict
 arch = ARCHS["ViT-B/16"]
-clip = FrozenCLIP(make_state_dict(arch, 1))
+clip = FrozenCLIP(make_state_dict(arch, 1), precision=os.environ.get("PREC", "split_grad"))
 eng = clip.engine
 C, L, n = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 77, 16
 nl = [1 + (i % 3) for i in range(C)]
