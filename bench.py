@@ -52,38 +52,72 @@ def algorithmic_gflop_per_image(arch, B_global, C, L_text, n_ctx, n_vpt, causal_
     return (img + head + txt / B_global) / 1e9
 
 
-def cpu_baseline_images_per_sec(arch, sd, B, C, L, n_ctx, sample_images=8):
-    """Oracle (CPU restatement, kind "port") on the host cores: image tower forward on a bounded sample of the
-    batch (extrapolated linearly, it is per-image independent) + the FULL text tower fwd+bwd + head."""
+def cpu_baseline_images_per_sec(arch, sd, C, L, n_ctx, pre, B_cpu=64, steps=3):
+    """Oracle (CPU restatement, kind "port") on the host cores, as BASELINE.md §3 asks: a B = 64 slice of the workload,
+    one warm-up step, then >= 3 timed FULL steps (image tower forward, text tower forward + backward over all classes, cosine
+    logits, cross-entropy, prompt gradient)."""
     from oracle import clip_oracle as O
     torch.manual_seed(0)
     threads = torch.get_num_threads()
-    img = torch.randn(sample_images, 3, arch.image_resolution, arch.image_resolution)
-    name_lens = [1 + (i % 3) for i in range(C)]
-    layout = O.build_prompt_layout(name_lens, n_ctx, L, "middle")
-    eot = torch.tensor([n_ctx + nl + 2 for nl in name_lens])
+    img = torch.randn(B_cpu, 3, arch.image_resolution, arch.image_resolution)
+    layout = O.build_prompt_layout(pre.name_lens, n_ctx, L, "middle")
+    eot = pre.tokenized_prompts[:, :L].argmax(dim=-1)
     prefix = torch.randn(C, 1, arch.transformer_width) * 0.02
     suffix = torch.randn(C, L - 1 - n_ctx, arch.transformer_width) * 0.02
     ctx = torch.randn(n_ctx, arch.transformer_width) * 0.02
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        feat, _ = O.image_encoder_fwd(sd, img, None, None, heads=arch.vision_heads, need_bwd=False)
-        t_img = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        prompts = O.assemble_prompts(ctx, prefix, suffix, layout)
-        txt, tctx = O.text_encoder_fwd(sd, prompts, eot, heads=arch.transformer_heads, need_bwd=True)
-        full = feat.repeat((B + sample_images - 1) // sample_images, 1)[:B]
-        logits, lctx = O.logits_fwd(full, txt, float(sd["logit_scale"].exp()))
-        loss, dl = O.cross_entropy_fwd_bwd(logits, torch.randint(0, C, (B,)))
-        _, dtxt = O.logits_bwd(dl, lctx)
-        dprompts = O.text_encoder_bwd(sd, dtxt, tctx)
-        O.scatter_prompt_grad(dprompts, layout, tuple(ctx.shape))
-        t_txt = time.perf_counter() - t0
-    step = t_img * (B / sample_images) + t_txt
-    return {"value": round(B / step, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle/clip_oracle.py fp32 on {threads} host threads: image-tower forward on {sample_images} of {B} "
-                      f"images ({t_img:.1f}s, extrapolated x{B // sample_images}) + full text tower fwd+bwd and head for "
-                      f"{C} classes L={L} ({t_txt:.1f}s)"}
+    label = torch.randint(0, C, (B_cpu,))
+    scale = float(sd["logit_scale"].exp())
+
+    def step():
+        with torch.no_grad():
+            feat, _ = O.image_encoder_fwd(sd, img, None, None, heads=arch.vision_heads, need_bwd=False)
+            prompts = O.assemble_prompts(ctx, prefix, suffix, layout)
+            txt, tctx = O.text_encoder_fwd(sd, prompts, eot, heads=arch.transformer_heads, need_bwd=True)
+            logits, lctx = O.logits_fwd(feat, txt, scale)
+            loss, dl = O.cross_entropy_fwd_bwd(logits, label)
+            _, dtxt = O.logits_bwd(dl, lctx)
+            O.scatter_prompt_grad(O.text_encoder_bwd(sd, dtxt, tctx), layout, tuple(ctx.shape))
+        return float(loss)
+
+    t0 = time.perf_counter()
+    step()
+    t_warm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    t = (time.perf_counter() - t0) / steps
+    return {"value": round(B_cpu / t, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle/clip_oracle.py (fp32 torch-CPU restatement, pinned by the reference fixtures) on {threads} host "
+                      f"threads: B = {B_cpu} slice of the workload ({C} classes, L = {L}), 1 warm-up step ({t_warm:.1f} s) + "
+                      f"{steps} timed full steps of {t:.2f} s (image tower forward, text tower forward+backward, head)"}
+
+
+class _CyclingLoader:
+    """`total` batches cycling over a few resident synthetic batches (what Dassl's DataLoader is to TrainerX.run_epoch)."""
+
+    def __init__(self, batches, total):
+        self.batches, self.total = batches, total
+
+    def __len__(self):
+        return self.total
+
+    def __iter__(self):
+        for i in range(self.total):
+            yield self.batches[i % len(self.batches)]
+
+
+def _respawn_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks ourselves (one process per GPU, RCCL), as the
+    reference gets its replicas from one process (nn.DataParallel, trainers/mvlpt.py:877-880)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
 
 
 def main():
@@ -101,6 +135,8 @@ def main():
     ap.add_argument("--no-step-pipelining", action="store_true",
                     help="do not compute the next batch's image features underneath the current backward")
     ap.add_argument("--shard-text", action="store_true", help="class-shard the text tower over the ranks (many-class configs)")
+    ap.add_argument("--multitask", action="store_true",
+                    help="ELEVATER-style multitask batch: per-task logit mask + soft labels (needs a multitask class list: 2191 / 1151 classes)")
     ap.add_argument("--grad-precision", default="split_grad", choices=["split_grad", "fast"],
                     help="split_grad (default): hi+lo operand pairs + fp32 attention in towers that carry a gradient (prompt "
                          "gradients within 1e-3 of the fp32 CPU path); fast: single 16-bit operands everywhere (~4e-3)")
@@ -109,6 +145,10 @@ def main():
     ap.add_argument("--all-kernel-timing", action="store_true", help="bracket every kernel class with marker events (slower)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn_under_torchrun(args.gpus)
+
+    from mvlpt_amd import class_prompts as CP
     from mvlpt_amd import distributed as D
     from mvlpt_amd.config import get_cfg_default
     from mvlpt_amd.trainer import MVLPT, SyntheticDataManager
@@ -116,8 +156,10 @@ def main():
 
     rank, world, local = D.init_process_group()
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s) "
+                         f"(launch with torch.distributed.run --nproc-per-node {args.gpus}, or let bench.py spawn them)")
+    if world > 1:
+        assert torch.distributed.is_initialized() and torch.distributed.get_world_size() == args.gpus
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
 
@@ -128,7 +170,10 @@ def main():
     cfg.DATALOADER.TRAIN_X.BATCH_SIZE = args.batch
     cfg.TRAINER.MVLPT.COMPUTE_DTYPE = args.dtype
     cfg.TRAINER.MVLPT.GRAD_PRECISION = args.grad_precision
+    cfg.TRAINER.MVLPT.STEP_PIPELINING = not args.no_step_pipelining
     cfg.TRAINER.CUT_CONTEXTLEN = args.cut
+    cfg.TRAIN.PRINT_FREQ = 10 ** 9          # no host read-back of the loss inside the timed region
+    cfg.OPTIM.MAX_EPOCH = 10 ** 6
     n_ctx = n_vpt = 0
     if args.method in ("coop", "upt"):
         n_ctx = 16 if args.method == "coop" else 4
@@ -137,100 +182,103 @@ def main():
     cfg.TRAINER.MVLPT.COOP.N_CTX, cfg.TRAINER.MVLPT.VPT.N_CTX = n_ctx, n_vpt
     cfg.SEED = 1
     sd = make_state_dict(arch, seed=1)
+    # class prompts: the reference tokenizer's own ids for the BASELINE class lists (mvlpt_amd/data/class_prompts.npz)
+    list_name = CP.BY_CLASS_COUNT.get(args.classes)
+    pre, task_counts = None, None
+    if list_name is not None:
+        pre, _ = CP.load_class_prompts(list_name, n_ctx, cut_contextlen=args.cut, context_length=arch.context_length)
+        if args.multitask:
+            task_counts = CP.task_class_counts(list_name)
+            if len(task_counts) < 2:
+                raise SystemExit("--multitask needs a multitask class list (--classes 2191 or 1151)")
+            cfg.DATASET.MULTITASK = cfg.DATASET.MULTITASK_LABEL_PERTASK = True
+    elif args.multitask:
+        raise SystemExit("--multitask needs a multitask class list (--classes 2191 or 1151)")
     n_batches = 4
-    dm = SyntheticDataManager(cfg, args.classes, n_batches, device=dev, seed=1234 + rank)
+    W, K = args.warmup, args.steps
+    dm = SyntheticDataManager(cfg, args.classes, n_batches, task_class_counts=task_counts, device=dev, seed=1234 + rank,
+                              soft_labels=args.multitask)
+    dm.pretokenized = pre
+    dm.train_loader_x = _CyclingLoader(dm.train_loader_x, W + K + 1)
     trainer = MVLPT(cfg, dm=dm, clip_state_dict=sd)
-    trainer.num_batches = 10 ** 9   # no LR-schedule step inside the timed region
     trainer.model.trim_text_to_eot = args.trim_eot
     if args.shard_text and world > 1:
         trainer.model.enable_class_sharding(rank, world)
     L_text = trainer.model.prompt_learner.tokenized_prompts.shape[1]
     eng = trainer.model.engine
+    pipeline = cfg.TRAINER.MVLPT.STEP_PIPELINING and n_vpt == 0
 
-    pipeline = not args.no_step_pipelining
-
-    def step(i):
-        nonlocal_pipeline = pipeline
-        trainer.batch_idx = i
-        nxt = dm.train_loader_x[(i + 1) % n_batches] if nonlocal_pipeline else None
-        return trainer.forward_backward(dm.train_loader_x[i % n_batches], next_batch=nxt)
-
-    # Multi-rank runs: make sure the cross-step prefetch is a win on this system before the timed region (it changes
-    # how the gradient all-reduce interleaves with the side streams).  Untimed probe, 3 steps per mode, the decision is
-    # the same on every rank (MAX over ranks of each mode's time).
-    if pipeline and world > 1:
-        def probe(flag):
-            nonlocal pipeline
-            pipeline = flag
-            step(0)
-            torch.cuda.synchronize(); D.barrier()
-            t = time.perf_counter()
-            for i in range(3):
-                step(i)
-            torch.cuda.synchronize()
-            return D.all_reduce_max(time.perf_counter() - t, dev)
-        t_pipe, t_plain = probe(True), probe(False)
-        pipeline = t_pipe <= 1.15 * t_plain       # only a clear loss switches it off (3-step probes are noisy)
-        if rank == 0 and not pipeline:
-            print(f"note: cross-step prefetch disabled (probe: {t_pipe / 3 * 1e3:.2f} ms/step with, {t_plain / 3 * 1e3:.2f} without)",
-                  file=sys.stderr)
-
-    for i in range(args.warmup):
-        out = step(i)
-    torch.cuda.synchronize()
-    D.barrier()
-    torch.cuda.synchronize()
+    # The timed region is K steps of the trainer's OWN loop (TrainerX.run_epoch, which reads the loader one batch ahead):
+    # the hook below brackets steps W .. W+K-1 with barrier + synchronize on both sides.  Every timed step contains
+    # exactly one image tower (the prefetch of the following batch), one text tower forward + backward, the head, the
+    # gradient all-reduce and the SGD update; the loop is stopped before step W+K runs.
     timing = not args.no_kernel_timing
-    if timing:
-        eng.profile_begin(all_kernels=args.all_kernel_timing)
     sample_every = 1 if args.all_kernel_timing else 4     # dispatch-timestamp timing costs ~2 us per launch: sample steps
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if timing:
-            eng.profile_pause(i % sample_every != 0)
-        out = step(i)
-    torch.cuda.synchronize()
-    D.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    mark = {}
+
+    def fence():
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+
+    def hook(i):
+        if i == W:
+            fence()
+            if timing:
+                eng.profile_begin(all_kernels=args.all_kernel_timing)
+            mark["t0"] = time.perf_counter()
+        if i == W + K:
+            fence()
+            mark["t1"] = time.perf_counter()
+            return False
+        if timing and i >= W:
+            eng.profile_pause((i - W) % sample_every != 0)
+        return True
+
+    trainer.batch_hook = hook
+    out = trainer.run_epoch()
+    trainer.batch_hook = None
+    elapsed = mark["t1"] - mark["t0"]
     stats = eng.profile_end() if timing else {}
     elapsed = D.all_reduce_max(elapsed, dev)
-    # Untimed extra pass: the same step with the two towers serialized on one stream, so each GEMM launch has the
-    # chip to itself.  In the timed region above the text tower runs on a second stream underneath the image
-    # tower; concurrent kernels stretch each other's durations, which inflates per-launch times (they then sum
+    # Untimed extra pass: the same step with the two towers serialized on one stream and no cross-step prefetch, so each
+    # GEMM launch has the chip to itself.  In the timed region the text tower runs on a second stream underneath the
+    # image tower; concurrent kernels stretch each other's durations, which inflates per-launch times (they then sum
     # to more than the step) without being slower overall.  Reported next to the timed-region figure.
     stats_serial = {}
     if timing and trainer.model.overlap_towers:      # every rank takes part (the step contains the gradient all-reduce)
         trainer.model.overlap_towers = False
-        pipeline_saved, pipeline = pipeline, False       # no cross-step prefetch either: strictly one kernel at a time
-        step(0)
+        cfg.TRAINER.MVLPT.STEP_PIPELINING = False
+        batches = dm.train_loader_x.batches
+        trainer.forward_backward(batches[0])
         torch.cuda.synchronize()
         eng.profile_begin(all_kernels=False)
         for i in range(3):
-            step(i)
+            trainer.forward_backward(batches[i % n_batches])
         torch.cuda.synchronize()
         stats_serial = eng.profile_end()
         trainer.model.overlap_towers = True
-        pipeline = pipeline_saved
     loss = float(out["loss"])
     assert loss == loss, "loss is NaN"
 
     if rank == 0:
         B_global = args.batch * world
-        ips = B_global * args.steps / elapsed
+        ips = B_global * K / elapsed
         L_alg = (trainer.model.prompt_learner.max_eot + 1) if args.trim_eot else L_text   # charge only evaluated positions
         gf_img = algorithmic_gflop_per_image(arch, B_global, args.classes, L_alg, n_ctx, n_vpt)
+        is_headline = (args.method, args.arch, args.classes, args.batch, args.cut, args.multitask) == ("coop", "ViT-B/16", 100, 256, False, False)
         line = {
             "metric": "prompt-tuning images/sec (fwd+bwd), ViT-B/16 bs=256, 1/2/4/8 MI355X",
-            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(1e3 * elapsed / K, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (("BASELINE configs[1]: " if (args.method, args.arch, args.classes, args.batch) ==
-                                     ("coop", "ViT-B/16", 100, 256) else "variant: ") +
-                                    f"MVLPT {args.method} head, {args.arch}, {args.classes} classes, "
-                                    f"n_ctx={n_ctx} n_vpt={n_vpt}, text L={L_text}, class token middle"),
+            "config": {"workload": (("BASELINE configs[1]: " if is_headline else "variant: ") +
+                                    f"MVLPT {args.method} head, {args.arch}, {args.classes} classes"
+                                    f"{' (' + list_name + ' token table)' if list_name else ' (synthetic token ids)'}, "
+                                    f"n_ctx={n_ctx} n_vpt={n_vpt}, text L={L_text}, class token middle"
+                                    f"{', per-task mask + soft labels' if args.multitask else ''}"),
                        "text_positions_evaluated": (trainer.model.prompt_learner.max_eot + 1) if args.trim_eot else L_text,
-                       "step_pipelining": bool(pipeline and n_vpt == 0),
+                       "loop": "TrainerX.run_epoch (reads one batch ahead)", "step_pipelining": bool(pipeline),
                        "grad_precision": args.grad_precision,
                        "per_gpu_batch": args.batch, "global_batch": B_global, "parallelism": f"dp{world}",
                        "text_tower": "class-sharded over ranks" if (args.shard_text and world > 1) else "replicated per GPU", "loss": round(loss, 5)},
@@ -238,10 +286,10 @@ def main():
             "algorithmic_gflop_per_image": round(gf_img, 3),
         }
         traffic = None
-        if os.path.isfile(TRAFFIC_FILE) and args.method == "coop" and args.batch == 256:
+        if os.path.isfile(TRAFFIC_FILE) and is_headline:
             with open(TRAFFIC_FILE) as f:
                 traffic = json.load(f)       # {"bytes_per_launch": …, "source": "rocprofv3 --pmc …"} (offline PMC passes)
-        n_sampled = len(range(0, args.steps, sample_every))
+        n_sampled = len(range(0, K, sample_every))
         if "gemm_bt" in stats:
             g = stats["gemm_bt"]
             # achieved = algorithmic FLOPs of the launches / time during which the kernel occupies the GPU.  The text
@@ -256,17 +304,27 @@ def main():
                                 "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
                                 "busy_us_per_launch": round(1e3 * g["busy_ms"] / g["launches"], 2),
                                 "achieved_sum_of_durations": round(tf_sum, 1),
+                                "executed_over_algorithmic_flops": round(g["flops_executed"] / g["flops"], 4),
+                                "achieved_executed": round(g["flops_executed"] / (g["busy_ms"] * 1e-3) / 1e12, 1),
                                 "algorithmic_bytes_per_launch": int(g["bytes"] / g["launches"]),
-                                "concurrency": "timed region: text tower on a 2nd stream and the next batch's image tower on a 3rd overlap; achieved = FLOPs / union of the launch intervals"}
+                                "concurrency": "timed region: text tower on a 2nd stream and the next batch's image tower on a 3rd overlap; achieved = FLOPs / union of the launch intervals",
+                                "note": "achieved / frac charge ALGORITHMIC FLOPs (2MNK per linear); launches with split-precision operands execute twice that (achieved_executed)"}
             if "gemm_bt" in stats_serial:
                 gs = stats_serial["gemm_bt"]
                 tfs = gs["flops"] / (gs["ms"] * 1e-3) / 1e12
                 line["roofline"]["serialized_towers"] = {"achieved": round(tfs, 1), "frac": round(tfs / MFMA_PEAK_TFLOPS, 4),
+                                                         "achieved_executed": round(gs["flops_executed"] / (gs["ms"] * 1e-3) / 1e12, 1),
                                                          "avg_launch_us": round(1e3 * gs["ms"] / gs["launches"], 2),
                                                          "note": "3 untimed steps, everything on one stream, no cross-step prefetch"}
             line["kernel_ms_per_step"] = {k: round(v["ms"] / n_sampled, 3) for k, v in stats.items()}
-        if world == 1 and not args.no_cpu_baseline and args.method == "coop":
-            line["cpu_baseline"] = cpu_baseline_images_per_sec(arch, sd, args.batch, args.classes, L_text, n_ctx)
+            # executed (not algorithmic) step-level fraction: GEMM FLOPs actually issued per step (CLS-only / EOT-only last
+            # blocks skip work the reference computes and never reads; split-precision GEMMs issue twice their 2MNK)
+            # plus the attention FLOPs at their algorithmic count
+            att = (args.batch * arch.vision_layers * 4 * (1 + n_vpt + arch.grid ** 2) ** 2 * arch.vision_width * (3 if n_vpt else 1)
+                   + (args.classes * arch.transformer_layers * 2 * L_text ** 2 * arch.transformer_width * 3 if n_ctx else 0))
+            line["step_mfma_fraction_executed"] = round((g["flops_executed"] / n_sampled + att) / (elapsed / K) / (MFMA_PEAK_TFLOPS * 1e12), 4)
+        if world == 1 and not args.no_cpu_baseline and args.method == "coop" and pre is not None:
+            line["cpu_baseline"] = cpu_baseline_images_per_sec(arch, sd, args.classes, L_text, n_ctx, pre)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

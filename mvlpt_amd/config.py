@@ -66,6 +66,9 @@ def get_cfg_default() -> CfgNode:
         # not in the reference: "split_grad" (default: hi+lo operand pairs + fp32 attention in towers that carry a
         # gradient: prompt gradients within 1e-3 of the fp32 CPU path) | "fast" (single 16-bit operands, ~4e-3)
         GRAD_PRECISION="split_grad",
+        # not in the reference: compute the NEXT batch's image features underneath the current text-tower backward when
+        # the method has no visual prompts (TrainerX.run_epoch reads the loader one batch ahead)
+        STEP_PIPELINING=True,
     )
     cfg.DATASET = CN(NAME="synthetic", COOP=True, MULTITASK=False, MULTITASK_LABEL_PERTASK=False,
                      MULTITASK_EVALKEY="average", NUM_SHOTS=16)

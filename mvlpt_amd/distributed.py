@@ -41,6 +41,22 @@ def init_process_group(backend: str | None = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def _host_staged() -> bool:
+    """gloo moves host memory: device tensors are staged through the host (debug mode MVLPT_DEBUG_SHARE_GPU and CPU tests
+    only; RCCL works on device memory directly)."""
+    return dist.is_initialized() and dist.get_backend() == "gloo"
+
+
+def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
+    if _host_staged() and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int) -> None:
     """grad <- mean over ranks, through one flat buffer (each rank's loss is the mean over its own slice, all
     slices have the same size, so the mean of rank gradients is the gradient of the global-batch mean loss)."""
@@ -48,7 +64,7 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int) 
     if world_size <= 1 or not grads:
         return
     flat = torch.cat([g.reshape(-1).float() for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    all_reduce_sum_(flat)
     flat.mul_(1.0 / world_size)
     off = 0
     for g in grads:
@@ -64,7 +80,12 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
     if not tensors:
         return
     flat = torch.cat([t.reshape(-1).float() for t in tensors])
-    dist.broadcast(flat, src=src)
+    if _host_staged() and flat.is_cuda:
+        h = flat.cpu()
+        dist.broadcast(h, src=src)
+        flat.copy_(h)
+    else:
+        dist.broadcast(flat, src=src)
     off = 0
     for t in tensors:
         n = t.numel()
@@ -80,6 +101,6 @@ def barrier() -> None:
 def all_reduce_max(value: float, device) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if _host_staged() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

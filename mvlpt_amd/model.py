@@ -310,8 +310,15 @@ def _gather_class_shards(loc: torch.Tensor, bounds, cmax: int) -> torch.Tensor:
     e, world = loc.shape[1], len(bounds)
     pad = torch.zeros(cmax, e, device=loc.device, dtype=loc.dtype)
     pad[:loc.shape[0]] = loc
-    out = torch.empty(world * cmax, e, device=loc.device, dtype=loc.dtype)
-    dist.all_gather_into_tensor(out, pad)
+    if dist.get_backend() == "gloo":          # CPU tests / one-GPU debug mode: host-staged all-reduce of disjoint slots
+        out = torch.zeros(world * cmax, e, dtype=loc.dtype)
+        r = dist.get_rank()
+        out[r * cmax:(r + 1) * cmax] = pad.cpu()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        out = out.to(loc.device)
+    else:
+        out = torch.empty(world * cmax, e, device=loc.device, dtype=loc.dtype)
+        dist.all_gather_into_tensor(out, pad)
     return torch.cat([out[r * cmax:r * cmax + (hi - lo)] for r, (lo, hi) in enumerate(bounds)], dim=0)
 
 
@@ -322,9 +329,10 @@ def _scatter_class_grads(dtxt: torch.Tensor, bounds, cmax: int, rank: int) -> to
     buf = torch.zeros(world * cmax, e, device=dtxt.device, dtype=dtxt.dtype)
     for r, (lo, hi) in enumerate(bounds):
         buf[r * cmax:r * cmax + (hi - lo)] = dtxt[lo:hi]
-    if dist.get_backend() == "gloo":          # CPU tests: gloo has no reduce_scatter
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        own = buf[rank * cmax:(rank + 1) * cmax]
+    if dist.get_backend() == "gloo":          # CPU tests / one-GPU debug mode: gloo has no reduce_scatter; host-staged
+        h = buf.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        own = h[rank * cmax:(rank + 1) * cmax].to(dtxt.device)
     else:
         own = torch.empty(cmax, e, device=dtxt.device, dtype=dtxt.dtype)
         dist.reduce_scatter_tensor(own, buf, op=dist.ReduceOp.SUM)

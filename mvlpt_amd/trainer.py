@@ -126,6 +126,7 @@ class TrainerX:
         self.max_epoch = cfg.OPTIM.MAX_EPOCH
         self.output_dir = cfg.OUTPUT_DIR
         self.batch_idx, self.num_batches = 0, 0
+        self.next_batch, self.batch_hook = None, None
         self.check_cfg(cfg)
         self.build_data_loader()
         self.build_model()
@@ -196,10 +197,23 @@ class TrainerX:
                 self.save_model(self.epoch, self.output_dir)
 
     def run_epoch(self):
+        """One pass over train_loader_x (Dassl run_epoch).  The loader is read ONE BATCH AHEAD: while
+        step i runs, `self.next_batch` holds batch i+1, so a trainer whose forward has a batch-independent half (MVLPT
+        without visual prompts: the image features are a pure function of the image) can start it underneath the
+        current backward.  `forward_backward(batch)` keeps the reference's one-argument signature.
+        `self.batch_hook(batch_idx)` (optional) runs before every step: bench.py uses it to place its timers."""
         self.set_model_mode("train")
         self.num_batches = len(self.train_loader_x)
         t0 = time.time()
-        for self.batch_idx, batch in enumerate(self.train_loader_x):
+        it = iter(self.train_loader_x)
+        nxt = next(it, None)
+        self.batch_idx = -1
+        while nxt is not None:
+            batch, nxt = nxt, next(it, None)
+            self.batch_idx += 1
+            self.next_batch = nxt
+            if self.batch_hook is not None and self.batch_hook(self.batch_idx) is False:
+                break
             summary = self.forward_backward(batch)
             if (self.batch_idx + 1) % self.cfg.TRAIN.PRINT_FREQ == 0 and self.rank == 0:
                 vals = {k: (float(v) if torch.is_tensor(v) else v) for k, v in summary.items()}
@@ -207,6 +221,8 @@ class TrainerX:
                     raise FloatingPointError("Loss is infinite or NaN!")
                 print(f"epoch [{self.epoch + 1}/{self.max_epoch}] batch [{self.batch_idx + 1}/{self.num_batches}] "
                       f"time {time.time() - t0:.2f}s " + " ".join(f"{k} {v:.4f}" for k, v in vals.items()))
+        self.next_batch = None
+        return summary if self.batch_idx >= 0 else None
 
     # hooks the concrete trainer provides
     def check_cfg(self, cfg):
@@ -309,6 +325,8 @@ class MVLPT(TrainerX):
     def build_model(self):
         cfg = self.cfg
         classnames = self.dm.dataset.classnames if cfg.DATASET.COOP else list(self.dm.lab2cname.values())
+        # token ids produced elsewhere (mvlpt_amd.class_prompts: reference-tokenizer tables for the BASELINE class lists)
+        pretok = getattr(self.dm, "pretokenized", None)
         sd = self._sd_arg
         if sd is None:
             # no network: synthetic frozen weights of the named architecture (clip/clip.py:57 would download)
@@ -317,7 +335,7 @@ class MVLPT(TrainerX):
         # GRAD_PRECISION = "fast" (not in the reference) drops the split operands altogether (gradients within ~4e-3)
         prec = "split_all" if cfg.TRAINER.MVLPT.PREC == "fp32" else cfg.TRAINER.MVLPT.GRAD_PRECISION
         clip_model = FrozenCLIP(sd, compute_dtype=cfg.TRAINER.MVLPT.COMPUTE_DTYPE, device=self.device, precision=prec)
-        self.model = CustomCLIP(cfg, classnames, clip_model, dm=self.dm)
+        self.model = CustomCLIP(cfg, classnames, clip_model, dm=self.dm, pretokenized=pretok)
         for name, param in self.model.named_parameters():               # :855-858 (the towers hold no nn.Parameters)
             if "prompt_learner" not in name:
                 param.requires_grad_(False)
@@ -331,17 +349,26 @@ class MVLPT(TrainerX):
         self.register_model("prompt_learner", self.model.prompt_learner, self.optim, self.sched)
         self.scaler = None    # the HIP backward scales its 16-bit activation gradients internally
 
-    def forward_backward(self, batch, next_batch=None):
-        """trainers/mvlpt.py:910-951.  `next_batch` (optional, not in the reference): lets the image features of the
-        following step be computed underneath this step's backward when the method has no visual prompts."""
-        image, label, tasks_ = self.parse_batch_train(batch)
+    def forward_backward(self, batch):
+        """trainers/mvlpt.py:910-951.  When the loop has read one batch ahead (`self.next_batch`, TrainerX.run_epoch) and
+        the method has no visual prompts, the image features of the following step are computed underneath this step's
+        text-tower backward (model.prefetch_image_features)."""
+        next_batch = self.next_batch if self.cfg.TRAINER.MVLPT.STEP_PIPELINING else None
+        ahead = getattr(self, "_parsed_ahead", None)
+        if ahead is not None and ahead[0] is batch:
+            image, label, tasks_ = ahead[1]          # parsed (and uploaded) during the previous step
+        else:
+            image, label, tasks_ = self.parse_batch_train(batch)
+        self._parsed_ahead = None
         if len(label.shape) > 1 and label.shape[-1] > 1:                # :914-916
             label = label.float()
             label = label / label.sum(dim=-1, keepdim=True)
         output = self.model(image, task=tasks_)
         loss = self.model.cross_entropy(output, label)                  # F.cross_entropy (:931) as a HIP kernel
         if next_batch is not None:
-            self.model.prefetch_image_features(self.parse_batch_train(next_batch)[0])
+            parsed = self.parse_batch_train(next_batch)        # the H2D copy of batch i+1 overlaps step i as well
+            self._parsed_ahead = (next_batch, parsed)
+            self.model.prefetch_image_features(parsed[0])
         self.model_backward_and_update(loss)
         # device tensors: no .item() sync inside the step (the reference syncs twice per step, :941-942)
         loss_summary = {"loss": loss.detach(), "acc": self.model.last_ncorrect[0] * (100.0 / output.shape[0])}

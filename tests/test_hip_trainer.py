@@ -110,19 +110,26 @@ def test_elevater_eval_branch_uses_the_task_metrics(tmp_path):
 
 
 def test_step_pipelining_is_transparent(tmp_path):
-    """Prefetching the next batch's image features under the backward must not change any result."""
-    import copy
+    """Prefetching the next batch's image features under the backward (TrainerX.run_epoch reads the loader one batch ahead)
+    must not change any result, and it must actually happen under the plain Dassl-style loop."""
     runs = []
     for pipe in (False, True):
         torch.manual_seed(0)                      # same prompt initialisation in both runs
         tr = make_trainer(tmp_path, "coop")
-        tr.set_model_mode("train")
-        tr.num_batches = 10 ** 9
+        tr.cfg.TRAINER.MVLPT.STEP_PIPELINING = pipe
+        tr.cfg.TRAIN.PRINT_FREQ = 10 ** 9
+        hits = []
+        orig = tr.model.engine.image_fwd
+        tr.model.engine.image_fwd = lambda *a, **k: (hits.append(torch.cuda.current_stream().cuda_stream), orig(*a, **k))[1]
         losses = []
-        for i in range(6):
-            tr.batch_idx = i
-            nxt = tr.train_loader_x[(i + 1) % 4] if pipe else None
-            losses.append(float(tr.forward_backward(tr.train_loader_x[i % 4], next_batch=nxt)["loss"]))
+        for tr.epoch in range(2):                 # two epochs of 4 batches through the real loop
+            out = tr.run_epoch()
+            losses.append(float(out["loss"]))
+        main = torch.cuda.current_stream().cuda_stream
+        if pipe:      # per epoch: the first batch on the main stream, the other three prefetched on the side stream
+            assert sum(h != main for h in hits) == 6 and len(hits) == 8, hits
+        else:
+            assert all(h == main for h in hits) and len(hits) == 8
         runs.append((losses, tr.model.prompt_learner.ctx.detach().cpu().clone()))
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     assert torch.equal(runs[0][1], runs[1][1])
