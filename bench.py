@@ -58,7 +58,21 @@ def cpu_baseline_images_per_sec(arch, sd, C, L, n_ctx, pre, B_cpu=64, steps=3):
     logits, cross-entropy, prompt gradient)."""
     from oracle import clip_oracle as O
     torch.manual_seed(0)
-    threads = torch.get_num_threads()
+    # thread count: torch defaults to every hardware thread, which is far from the fastest setting on a many-core host
+    # (2 x 64-core EPYC: 16 threads run the oracle 4.7x faster than 128) — pick the best of a few counts on a small probe
+    probe = torch.randn(4, 3, arch.image_resolution, arch.image_resolution)
+    best = None
+    for th in sorted({min(c, os.cpu_count() or 1) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(th)
+        with torch.no_grad():
+            O.image_encoder_fwd(sd, probe[:1], None, None, heads=arch.vision_heads, need_bwd=False)
+            t0 = time.perf_counter()
+            O.image_encoder_fwd(sd, probe, None, None, heads=arch.vision_heads, need_bwd=False)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, th)
+    threads = best[1]
+    torch.set_num_threads(threads)
     img = torch.randn(B_cpu, 3, arch.image_resolution, arch.image_resolution)
     layout = O.build_prompt_layout(pre.name_lens, n_ctx, L, "middle")
     eot = pre.tokenized_prompts[:, :L].argmax(dim=-1)
@@ -88,7 +102,7 @@ def cpu_baseline_images_per_sec(arch, sd, C, L, n_ctx, pre, B_cpu=64, steps=3):
     t = (time.perf_counter() - t0) / steps
     return {"value": round(B_cpu / t, 3), "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": f"oracle/clip_oracle.py (fp32 torch-CPU restatement, pinned by the reference fixtures) on {threads} host "
-                      f"threads: B = {B_cpu} slice of the workload ({C} classes, L = {L}), 1 warm-up step ({t_warm:.1f} s) + "
+                      f"threads (fastest of 8/16/32/64 on a probe; the host has {os.cpu_count()} hardware threads): B = {B_cpu} slice of the workload ({C} classes, L = {L}), 1 warm-up step ({t_warm:.1f} s) + "
                       f"{steps} timed full steps of {t:.2f} s (image tower forward, text tower forward+backward, head)"}
 
 
