@@ -94,6 +94,15 @@ def run_case(mv, clip_model, *, name, image_size, classnames, B, case_seed, soft
         task = torch.randint(0, len(task_counts), (B,), generator=g)
         starts = np.concatenate([[0], np.cumsum(task_counts)[:-1]])
         label = torch.tensor([int(starts[t] + torch.randint(0, task_counts[t], (1,), generator=g)) for t in task.tolist()])
+        if soft_labels:
+            # ELEVATER multitask batches: multi-hot float targets inside the sample's own task range
+            # (trainers/mvlpt.py:914-916 normalises them; :573-581 masks the logits to the same range)
+            hot = torch.zeros(B, C)
+            for b, t in enumerate(task.tolist()):
+                lo, n = int(starts[t]), int(task_counts[t])
+                hot[b, lo:lo + n] = (torch.rand(n, generator=g) > 0.5).float()
+                hot[b, label[b]] = 1.0
+            label = hot
     elif soft_labels:
         label = (torch.rand(B, C, generator=g) > 0.6).float()
         label[torch.arange(B), torch.randint(0, C, (B,), generator=g)] = 1.0
@@ -164,11 +173,57 @@ def make_tiny(mv, cm):
              task_counts=[2, 1, 2], **common)
     run_case(mv, clip_model, name="tiny_soft_labels", case_seed=21, coop_n_ctx=4, class_token_position="end",
              soft_labels=True, **common)
+    # the ELEVATER-shaped combination (BASELINE cfg4/cfg5): UPT + per-task logit mask + soft multi-hot labels together
+    run_case(mv, clip_model, name="tiny_upt_mask_soft", case_seed=23, coop_n_ctx=4, vpt_n_ctx=2, vpt_deep=True, project_dim=64,
+             task_counts=[2, 1, 2], soft_labels=True, **common)
+    make_train_steps(mv, clip_model, arch)
     # CUT_CONTEXTLEN slices the shared causal masks in place (trainers/mvlpt.py:115-117): run LAST
     run_case(mv, clip_model, name="tiny_coop_cut", case_seed=15, coop_n_ctx=4, class_token_position="middle",
              cut_contextlen=True, **common)
     run_case(mv, clip_model, name="tiny_upt_cut", case_seed=22, coop_n_ctx=4, vpt_n_ctx=2, vpt_deep=True,
              project_dim=64, cut_contextlen=True, **common)
+
+
+def make_train_steps(mv, clip_model, arch):
+    """Train-step fixture: three `forward_backward` steps of the REFERENCE model — forward,
+    F.cross_entropy, backward (trainers/mvlpt.py:927-932) — with the optimizer Dassl's build_optimizer("sgd") makes
+    (torch.optim.SGD, momentum 0.9, weight_decay 5e-4, dampening 0, no nesterov — recalled Dassl defaults, SURVEY Appendix
+    B) over prompt_learner.parameters() (:869), one step per "epoch" so that the learning rate goes through the constant
+    warm-up -> base LR -> first cosine step (recalled Dassl ConstantWarmupScheduler + CosineAnnealingLR; configs/trainers/
+    MVLPT/vit_b16.yaml:15-22 with MAX_EPOCH = 3).  Stores inputs, initial and final parameters, losses."""
+    import math
+    cfg = ref_shim.make_cfg(input_size=arch.image_resolution, coop_n_ctx=4, vpt_n_ctx=2, vpt_deep=True, project_dim=64)
+    torch.manual_seed(51)
+    cc = mv.CustomCLIP(cfg, CLASSNAMES[:5], clip_model, dm=None)
+    for n_, p in cc.named_parameters():
+        p.requires_grad_("prompt_learner" in n_)
+    pl = cc.prompt_learner
+    base_lr, max_epoch, cons = 0.002, 3, 1e-5
+    lrs = [cons, base_lr, 0.5 * base_lr * (1 + math.cos(math.pi * 1 / max_epoch))]
+    opt = torch.optim.SGD(pl.parameters(), lr=base_lr, momentum=0.9, weight_decay=5e-4, dampening=0, nesterov=False)
+    g = torch.Generator().manual_seed(5100)
+    B = 4
+    d = {"lrs": np.array(lrs), "base_lr": np.float64(base_lr), "max_epoch": np.int64(max_epoch),
+         "tokenized_prompts": pl.tokenized_prompts.numpy().astype(np.int64), "name_lens": np.array(pl.name_lens, dtype=np.int64),
+         "token_prefix": pl.token_prefix.numpy(), "token_suffix": pl.token_suffix.numpy()}
+    for n_, p in pl.named_parameters():
+        d["init_" + n_] = p.detach().numpy().copy()
+    images, labels, losses = [], [], []
+    for step in range(3):
+        image = torch.randn(B, 3, arch.image_resolution, arch.image_resolution, generator=g)
+        label = torch.randint(0, 5, (B,), generator=g)
+        for grp in opt.param_groups:
+            grp["lr"] = lrs[step]
+        loss = F.cross_entropy(cc(image, task=None), label)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        images.append(image.numpy()); labels.append(label.numpy()); losses.append(float(loss))
+    d["images"], d["labels"], d["losses"] = np.stack(images), np.stack(labels), np.array(losses)
+    for n_, p in pl.named_parameters():
+        d["final_" + n_] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "tiny_train_steps.npz"), **d)
+    print(f"[golden] tiny_train_steps: losses {losses} lrs {lrs}")
 
 
 def make_full(mv, cm):
