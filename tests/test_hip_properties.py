@@ -18,7 +18,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _model(method="coop", C=100, n_ctx=16, n_vpt=8, arch_name="ViT-B/16", tasks=None, seed=0):
+def _model(method="coop", C=100, n_ctx=16, n_vpt=8, arch_name="ViT-B/16", tasks=None, seed=0, class_list=None):
     from mvlpt_amd.config import get_cfg_default
     from mvlpt_amd.model import CustomCLIP, FrozenCLIP
     from mvlpt_amd.weights import ARCHS, make_state_dict
@@ -44,7 +44,12 @@ def _model(method="coop", C=100, n_ctx=16, n_vpt=8, arch_name="ViT-B/16", tasks=
         dm = DM()
     torch.manual_seed(seed)
     names = [f"class number {i}" if i % 3 else f"c{i}" for i in range(C)]
-    model = CustomCLIP(cfg, names, FrozenCLIP(sd, "fp16"), dm=dm).cuda()
+    pre = None
+    if class_list is not None:       # the reference tokenizer's own ids for a BASELINE class list (mvlpt_amd/data/class_prompts.npz)
+        from mvlpt_amd.class_prompts import load_class_prompts
+        pre, n = load_class_prompts(class_list, T.COOP.N_CTX)
+        assert n == C
+    model = CustomCLIP(cfg, names, FrozenCLIP(sd, "fp16"), dm=dm, pretokenized=pre).cuda()
     return arch, model
 
 
@@ -206,3 +211,96 @@ def test_step_is_bitwise_deterministic(method, B):
         assert torch.equal(l0, l1) and torch.equal(s0, s1)
         for k in g0:
             assert torch.equal(g0[k], g1[k]), k
+
+
+# ---------------------------------------------------------------------------------------------- many-class configurations
+# BASELINE configs[2] (per-GPU shape: VPT-deep 8 tokens/layer, ImageNet-1k = 1000 classes, batch 256) and configs[3]
+# (UPT 4+4, the 11-dataset CoOp multitask set = 2191 classes, per-task logit mask AND soft labels together, batch 256),
+# with the reference tokenizer's ids for those class lists.  The oracle would need tens of minutes per step here.
+
+def test_cfg3_vpt_deep_1000_classes_batch_256():
+    arch, model = _model("vpt", C=1000, n_vpt=8, class_list="imagenet1k")
+    B = 256
+    x = _images(arch, B)
+    y = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(12)).cuda()
+
+    def run(scale=1.0):
+        model.zero_grad(set_to_none=True)
+        logits = model(x)
+        loss = model.cross_entropy(logits, y) * scale
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().clone(), float(loss.detach()), _grads(model)
+
+    l0, s0, g0 = run()
+    txt = model._const_text_features
+    assert txt is not None and txt.shape == (1000, 512), "no text context: the 1000 text features are constants and must be cached"
+    l1, s1, g1 = run()
+    assert model._const_text_features is txt, "cached text features must be reused, not recomputed every step"
+    assert torch.equal(l0, l1) and s0 == s1 and all(torch.equal(g0[k], g1[k]) for k in g0), "bitwise deterministic"
+    assert set(g0) == {"vpt_embeddings", "vpt_embeddings_deep"} and g0["vpt_embeddings_deep"].shape == (11, 8, 768)
+    _, s4, g4 = run(4.0)
+    for k in g0:
+        assert torch.isfinite(g0[k]).all() and float(g0[k].abs().max()) > 0
+        assert torch.equal(g4[k], 4.0 * g0[k]), f"{k}: 4x loss must give exactly 4x gradient"
+    assert l0.shape == (B, 1000) and float(l0.abs().max()) <= math.exp(math.log(1 / 0.07)) * (1 + 1e-5)
+    with torch.no_grad():      # (inference forwards run the single-operand mode: compare them with each other)
+        full = model(x)
+        halves = torch.cat([model(x[:128].contiguous()), model(x[128:].contiguous())])
+    assert torch.equal(halves, full)
+    assert float((full - l0).abs().max()) <= 1e-3 * float(l0.abs().max()), "training and inference forwards agree to 1e-3"
+    # cross-entropy at C = 1000 against torch on the same logits
+    ref = torch.nn.functional.cross_entropy(l0, y)
+    assert abs(float(ref) - s0) < 1e-5 * max(1.0, s0)
+
+
+def test_cfg4_upt_2191_classes_task_mask_and_soft_labels_batch_256():
+    from mvlpt_amd.class_prompts import task_class_counts
+    tasks = task_class_counts("coop11")
+    assert len(tasks) == 11 and sum(tasks) == 2191
+    arch, model = _model("upt", C=2191, n_ctx=4, n_vpt=4, tasks=tasks, class_list="coop11")
+    B, C = 256, 2191
+    x = _images(arch, B)
+    g = torch.Generator().manual_seed(13)
+    task = torch.randint(0, len(tasks), (B,), generator=g)
+    starts = torch.tensor([0] + list(torch.tensor(tasks).cumsum(0)[:-1]))
+    lo, hi = starts[task], starts[task] + torch.tensor(tasks)[task]
+    cols = torch.arange(C).view(1, -1)
+    inside = (cols >= lo.view(-1, 1)) & (cols < hi.view(-1, 1))
+    soft = ((torch.rand(B, C, generator=g) > 0.7) & inside).float()
+    soft[torch.arange(B), lo + (torch.rand(B, generator=g) * (hi - lo)).long()] = 1.0      # at least one positive, in range
+    soft = (soft / soft.sum(-1, keepdim=True)).cuda()                                      # trainers/mvlpt.py:914-916
+
+    def run(scale=1.0):
+        model.zero_grad(set_to_none=True)
+        logits = model(x, task=task)
+        loss = model.cross_entropy(logits, soft) * scale
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().clone(), float(loss.detach()), _grads(model)
+
+    l0, s0, g0 = run()
+    assert l0.shape == (B, C) and torch.isfinite(l0).all()
+    assert float(l0[~inside.cuda()].abs().max()) == 0.0, "out-of-task logits are exactly 0 (multiplicative mask, :578-581)"
+    assert float(l0[inside.cuda()].abs().max()) > 0
+    # soft-label cross-entropy (probability targets) against torch on the same logits; masked zeros stay in the softmax
+    ref = torch.nn.functional.cross_entropy(l0, soft)
+    assert abs(float(ref) - s0) < 1e-5 * max(1.0, s0)
+    assert {"ctx", "vpt_embeddings", "vpt_embeddings_deep"} <= set(g0) and len(g0) == 23      # + 20 projection tensors (PROJECT_DIM 128: pre/post Linears on both sides)
+    _, _, g4 = run(4.0)
+    _, _, gz = run(0.0)
+    for k in g0:
+        assert torch.isfinite(g0[k]).all() and float(g0[k].abs().max()) > 0, k
+        assert float((g4[k] - 4.0 * g0[k]).abs().max()) <= 1e-5 * float(g4[k].abs().max()), k
+        assert float(gz[k].abs().max()) == 0.0, k
+    # descent direction: one small normalised SGD step lowers the (masked, soft-label) loss by the first-order amount
+    params = [p for p in model.prompt_learner.parameters() if p.requires_grad]
+    _, s_before, _ = run()
+    gnorm2 = sum(float((p.grad ** 2).sum()) for p in params)
+    step = 0.02 / math.sqrt(gnorm2)
+    with torch.no_grad():
+        for p in params:
+            p.add_(p.grad, alpha=-step)
+        s_after = float(model.cross_entropy(model(x, task=task), soft))
+    drop, predicted = s_before - s_after, step * gnorm2
+    assert drop > 0 and 0.5 * predicted < drop < 1.5 * predicted, (drop, predicted)
