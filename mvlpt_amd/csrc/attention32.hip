@@ -332,7 +332,7 @@ __global__ __launch_bounds__(SNT * 64) void attn32s_fwd_kernel(Attn32Args a) {
   for (int kt = 0; kt < SNT; ++kt)
     if (kt < kt_end) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { S[kt][r] = expf(S[kt][r] - mx); sum += S[kt][r]; }
+      for (int r = 0; r < 4; ++r) { S[kt][r] = __expf(S[kt][r] - mx); sum += S[kt][r]; }
     }
   sum = quad_sum32(sum);
   f32x4 O[4];
@@ -352,92 +352,93 @@ __global__ __launch_bounds__(SNT * 64) void attn32s_fwd_kernel(Attn32Args a) {
 
 template <typename T, bool CAUSAL>
 __global__ __launch_bounds__(SNT * 64) void attn32s_bwd_kernel(Attn32BwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem32[];
-  float* Qs = smem32;
-  float* Ks = Qs + SROWS * RS;
-  float* Vs = Ks + SROWS * RS;
-  float* Gs = Vs + SROWS * RS;                    // dO
-  float* lse_s = Gs + SROWS * RS;
-  float* del_s = lse_s + SROWS;
+  // Two LDS images (43.5 KiB: three workgroups per CU): K, V while the waves own query tiles (phase A: dQ), then Q, dO
+  // while they own key tiles (phase B: dK, dV).  The own rows live in registers in both phases.
+  __shared__ __attribute__((aligned(16))) float S0[SROWS * RS];
+  __shared__ __attribute__((aligned(16))) float S1[SROWS * RS];
+  __shared__ float lse_s[SROWS], del_s[SROWS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
   const int n = blockIdx.y, h = blockIdx.x, L = a.L, d = a.H * 64;
   const size_t ld = 3 * (size_t)d;
   const float* base = a.qkv + (size_t)n * L * ld + h * 64;
-  stage_rows(Qs, base, ld, L, tid, SNT * 64);
-  stage_rows(Ks, base + d, ld, L, tid, SNT * 64);
-  stage_rows(Vs, base + 2 * d, ld, L, tid, SNT * 64);
-  stage_rows(Gs, a.dout32 + (size_t)n * L * d + h * 64, d, L, tid, SNT * 64);
+  const float* gbase = a.dout32 + (size_t)n * L * d + h * 64;
+  stage_rows(S0, base + d, ld, L, tid, SNT * 64);          // K
+  stage_rows(S1, base + 2 * d, ld, L, tid, SNT * 64);      // V
   const size_t stat0 = ((size_t)n * a.H + h) * L;
   const int nt = (L + 15) >> 4;
   const int row = wave * 16 + fr, rc = row < L ? row : L - 1;     // own row: query in phase A, key in phase B
-  // delta = rowsum(dO * O) of the own query row, from global (dO fp32, O as a pair)
+  f32x4 Q[4], dO[4];
+  load_own(Q, base + (size_t)rc * ld, fg);
+  load_own(dO, gbase + (size_t)rc * d, fg);
+  // delta = rowsum(dO * O) of the own query row (O as a hi|lo pair)
   float dl = 0.f;
   {
     const T* orow = (const T*)a.out_split + ((size_t)n * L + rc) * (2 * (size_t)d) + h * 64;
-    const float* grow = a.dout32 + ((size_t)n * L + rc) * d + h * 64;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const f32x4 o = load_pair4<T>(orow + 16 * t + 4 * fg, d);
-      const f32x4 g = *(const f32x4*)(grow + 16 * t + 4 * fg);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dl += o[e] * g[e];
+      for (int e = 0; e < 4; ++e) dl += o[e] * dO[t][e];
     }
     dl = quad_sum32(dl);
   }
   const float lse = a.lse[stat0 + rc];
   if (fg == 0) { lse_s[row] = lse; del_s[row] = dl; }
   __syncthreads();
-  if (wave >= nt) return;
+  const bool active = wave < nt;
   T* orow = (T*)a.dqkv_split + ((size_t)n * L + rc) * (6 * (size_t)d) + h * 64;
+  f32x4 K[4], V[4];
   // ---- phase A: own query tile -> dQ
-  {
-    f32x4 Q[4], dO[4], dQ[4];
-    load_own(Q, Qs + row * RS, fg);
-    load_own(dO, Gs + row * RS, fg);
+  if (active) {
+    f32x4 dQ[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dQ[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int kt_end = CAUSAL ? wave + 1 : nt;
 #pragma unroll
     for (int kt = 0; kt < SNT; ++kt)
       if (kt < kt_end) {
-        f32x4 S = mm_tile(Ks, kt, Q, fr, fg);
-        const f32x4 dP = mm_tile(Vs, kt, dO, fr, fg);
+        f32x4 S = mm_tile(S0, kt, Q, fr, fg);
+        const f32x4 dP = mm_tile(S1, kt, dO, fr, fg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kk = 16 * kt + 4 * fg + r;
           const bool ok = kk < L && (!CAUSAL || kk <= row);
-          const float p = ok ? expf(S[r] * SCALE - lse) : 0.f;
+          const float p = ok ? __expf(S[r] * SCALE - lse) : 0.f;
           S[r] = p * (dP[r] - dl);
         }
-        accum_tile(dQ, Ks, kt, S, fr, fg);
+        accum_tile(dQ, S0, kt, S, fr, fg);
       }
     if (row < L) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, 3 * (size_t)d, dQ[dt] * SCALE);
     }
+    load_own(K, S0 + row * RS, fg);                        // own key row for phase B, before the images are replaced
+    load_own(V, S1 + row * RS, fg);
   }
+  __syncthreads();
+  stage_rows(S0, base, ld, L, tid, SNT * 64);              // Q
+  stage_rows(S1, gbase, d, L, tid, SNT * 64);              // dO
+  __syncthreads();
   // ---- phase B: own key tile -> dK, dV
-  {
-    f32x4 K[4], V[4], dK[4], dV[4];
-    load_own(K, Ks + row * RS, fg);
-    load_own(V, Vs + row * RS, fg);
+  if (active) {
+    f32x4 dK[4], dV[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dK[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int qt = 0; qt < SNT; ++qt)
       if (qt < nt && (!CAUSAL || qt >= wave)) {
-        f32x4 S = mm_tile(Qs, qt, K, fr, fg);            // lane: [key = fr][query = 16qt + 4fg + r]
-        f32x4 dP = mm_tile(Gs, qt, V, fr, fg);
+        f32x4 S = mm_tile(S0, qt, K, fr, fg);            // lane: [key = fr][query = 16qt + 4fg + r]
+        f32x4 dP = mm_tile(S1, qt, V, fr, fg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qq = 16 * qt + 4 * fg + r;
           const bool ok = qq < L && row < L && (!CAUSAL || row <= qq);
-          const float p = ok ? expf(S[r] * SCALE - lse_s[qq]) : 0.f;
+          const float p = ok ? __expf(S[r] * SCALE - lse_s[qq]) : 0.f;
           S[r] = p;
           dP[r] = p * (dP[r] - del_s[qq]);
         }
-        accum_tile(dV, Gs, qt, S, fr, fg);
-        accum_tile(dK, Qs, qt, dP, fr, fg);
+        accum_tile(dV, S1, qt, S, fr, fg);
+        accum_tile(dK, S0, qt, dP, fr, fg);
       }
     if (row < L) {
 #pragma unroll
@@ -466,16 +467,9 @@ static hipError_t fwd_t(const Attn32Args& a, hipStream_t s) {
 template <typename T>
 static hipError_t bwd_t(const Attn32BwdArgs& a, hipStream_t s) {
   if (a.L <= SROWS) {
-    constexpr int LDS = (4 * SROWS * RS + 2 * SROWS) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)attn32s_bwd_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)attn32s_bwd_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      attr_set = true;
-    }
     dim3 grid(a.H, a.N), block(SNT * 64);
-    if (a.causal) hipLaunchKernelGGL((attn32s_bwd_kernel<T, true>), grid, block, LDS, s, a);
-    else hipLaunchKernelGGL((attn32s_bwd_kernel<T, false>), grid, block, LDS, s, a);
+    if (a.causal) hipLaunchKernelGGL((attn32s_bwd_kernel<T, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn32s_bwd_kernel<T, false>), grid, block, 0, s, a);
     return hipGetLastError();
   }
   dim3 grid((a.L + CH - 1) / CH, a.H, a.N), block(256);

@@ -29,16 +29,28 @@ using namespace mvlpt;
 namespace {
 
 // ------------------------------------------------------------------------------------------------ small utils
+// Grow-only workspace.  Growth (a larger batch / class count than anything seen so far) must not stall the streams: work
+// that was enqueued on ANY stream may still be using the old block, so it is neither synchronised on nor freed here — it
+// is retired and released with the handle (1.5x geometric growth bounds the retired total by 2x the final size; the
+// 288 GB of HBM are not the constraint, a device-wide sync in the middle of a step would be).
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  std::vector<void*> retired;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+    for (void* q : retired) (void)hipFree(q);
+  }
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
-    if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e == hipSuccess) cap = bytes;
-    return e;
+    size_t got = std::max(bytes, cap + cap / 2);
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, got);
+    if (e != hipSuccess && got > bytes) { got = bytes; e = hipMalloc(&q, got); }      // the slack did not fit: exact size
+    if (e != hipSuccess) return e;
+    if (p) retired.push_back(p);
+    p = q; cap = got;
+    return hipSuccess;
   }
 };
 struct Bump {
