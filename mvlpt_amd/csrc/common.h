@@ -32,22 +32,6 @@ __device__ __forceinline__ f32x4 mfma16<bf16>(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-// D(32x32, f32) += A(32x16) * B(16x32), 16-bit inputs (gfx950: v_mfma_f32_32x32x16_{f16,bf16}; ~11 % higher MAC rate than
-// the 16x16x32 form and half as many issue slots per FLOP).  Operand layout (wave64):
-//   A: lane l holds A[row = l&31][k = 8*(l>>5) + 0..7]      B: lane l holds B[k = 8*(l>>5) + 0..7][col = l&31]
-//   D: lane l holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31], r = 0..15
-template <typename T>
-__device__ __forceinline__ f32x16 mfma_32x32(typename Vec<T>::v8 a, typename Vec<T>::v8 b, f32x16 c);
-template <>
-__device__ __forceinline__ f32x16 mfma_32x32<f16>(f16x8 a, f16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ f32x16 mfma_32x32<bf16>(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return static_cast<float>(v); }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return static_cast<T>(v); }
 

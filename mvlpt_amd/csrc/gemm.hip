@@ -384,307 +384,6 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
   }
 }
 
-// ---------------------------------------------------------------------------------------------- 32x32x16 variant
-// Same persistent pipeline (LDS-DMA ring across tile boundaries, counted vmcnt, XCD-aware tile order) with the
-// v_mfma_f32_32x32x16 form: ~11 % more MACs per matrix-pipe cycle than 16x16x32 (2178 vs 1955 TF f16 ceilings) and half
-// the issue slots per FLOP in a loop whose waves are issue-stalled 40-47 % of their cycles.
-//   LDS image: 128-B rows (64 k); 16-byte chunk c of tile row r lives at chunk  c ^ ((r >> 1) & 7): a ds_read_b128 lane
-//   group (16 lanes of one 32-row fragment, same k chunk) then touches 16 different 16-byte slots of the 256-B bank row
-//   (slot = 8*(r & 1) + chunk').  The swizzle is applied to the per-lane DMA SOURCE column (the LDS image is lane-linear).
-//   Operands are swapped (D = Bfrag x Afrag): lane l holds output row m = l & 31 and columns 8*(reg>>2) + 4*(l>>5) + (reg&3).
-// The epilogue transposes each 32-row block through the wave's private LDS scratch as before (16-bit: 32 rows x 64 cols,
-// fp32: 32 rows x 32 cols per pass) so that global traffic is full 128-byte row segments.
-template <typename T, int EPI, typename Rows16, typename Rows32>
-__device__ __forceinline__ void epilogue_store32(const GemmArgs& g, const f32x16 (&acc)[2][2], int mbase, int nbase, int lane,
-                                                 Rows16 rows16, Rows32 rows32) {
-  using v4 = typename Vec<T>::v4;
-  using v8 = typename Vec<T>::v8;
-  const int M = g.M, N = g.N;
-  const int lr = lane & 31, lh = lane >> 5;
-  auto quad = [&](int rb, int cb, int q) {
-    const f32x16& a = acc[rb][cb];
-    return f32x4{a[q * 4 + 0], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
-  };
-  if constexpr (EPI == EPI_STORE16 || EPI == EPI_GELU) {
-    f32x4 bv[2][4];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bv[cb][q] = g.bias ? *(const f32x4*)(g.bias + nbase + cb * 32 + q * 8 + lh * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int NOUT = (EPI == EPI_GELU) ? 2 : 1;
-#pragma unroll
-    for (int which = 0; which < NOUT; ++which) {
-      T* outp = (T*)(which == 0 ? g.out : g.out2);
-      if (which == 1 && !outp) break;
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 v = quad(rb, cb, q) + bv[cb][q];
-            v4 w;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = from_f32<T>((EPI == EPI_GELU && which == 0) ? quick_gelu(v[e]) : v[e]);
-            *(v4*)(rows16(lr) + (cb * 32 + q * 8 + lh * 4) * 2) = w;
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int r = it * 8 + (lane >> 3), c = lane & 7;   // 8 lanes x 16 B = one 128-B row segment
-          const v8 w = *(const v8*)(rows16(r) + c * 16);
-          const int m = mbase + rb * 32 + r;
-          if (m < M) __builtin_nontemporal_store(w, (v8*)(outp + (size_t)m * N + nbase + c * 8));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-    }
-  } else {
-    const int c = lane & 7, rq = lane >> 3;                   // 8 lanes x 16 B = one 128-B row segment (32 fp32 columns)
-    // the bias is added AFTER the transposition: there a lane owns one fixed 4-column chunk per 32-column block
-    f32x4 bvc[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) bvc[cb] = g.bias ? *(const f32x4*)(g.bias + nbase + cb * 32 + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 rv[2][2][4];
-    v4 uv[2][2][4];
-    if constexpr (EPI == EPI_RESID32 || EPI == EPI_GELUBWD || EPI == EPI_GELUBWD_SPLIT) {
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            int m = mbase + rb * 32 + it * 8 + rq;
-            m = m < M ? m : M - 1;
-            const size_t o = (size_t)m * N + nbase + cb * 32 + c * 4;
-            if constexpr (EPI == EPI_RESID32) rv[rb][cb][it] = __builtin_nontemporal_load((const f32x4*)(g.resid + o));
-            else uv[rb][cb][it] = __builtin_nontemporal_load((const v4*)((const T*)g.aux + o));
-          }
-    }
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *(f32x4*)(rows32(lr) + (q * 8 + lh * 4) * 4) = quad(rb, cb, q);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int r = it * 8 + rq;
-          f32x4 v = *(const f32x4*)(rows32(r) + c * 16) + bvc[cb];
-          const int m = mbase + rb * 32 + r;
-          const size_t o = (size_t)m * N + nbase + cb * 32 + c * 4;
-          if constexpr (EPI == EPI_RESID32) {
-            v += rv[rb][cb][it];
-            if (m < M) __builtin_nontemporal_store(v, (f32x4*)((float*)g.out + o));
-          } else if constexpr (EPI == EPI_GELUBWD) {
-            v4 w;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(v[e] * quick_gelu_grad(to_f32<T>(uv[rb][cb][it][e])));
-            if (m < M) __builtin_nontemporal_store(w, (v4*)((T*)g.out + o));
-          } else if constexpr (EPI == EPI_GELU_SPLIT || EPI == EPI_GELUBWD_SPLIT) {
-            v4 hi, lo, u16;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float r2;
-              if constexpr (EPI == EPI_GELU_SPLIT) { r2 = quick_gelu(v[e]); u16[e] = from_f32<T>(v[e]); }
-              else r2 = v[e] * quick_gelu_grad(to_f32<T>(uv[rb][cb][it][e]));
-              T h, l;
-              split16<T>(r2, h, l);
-              hi[e] = h; lo[e] = l;
-            }
-            if (m < M) {
-              T* row = (T*)g.out + (size_t)m * (2 * N) + nbase + cb * 32 + c * 4;
-              __builtin_nontemporal_store(hi, (v4*)row);
-              __builtin_nontemporal_store(lo, (v4*)(row + N));
-              if constexpr (EPI == EPI_GELU_SPLIT) { if (g.out2) __builtin_nontemporal_store(u16, (v4*)((T*)g.out2 + o)); }
-            }
-          } else {  // EPI_STORE32
-            if (m < M) __builtin_nontemporal_store(v, (f32x4*)((float*)g.out + o));
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-  }
-}
-
-template <typename T, int EPI, int BM_, int BN_, int NW, int NS>
-__global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt32_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  using v8 = typename Vec<T>::v8;
-  constexpr int BN = BN_;
-  constexpr int WCN = BN_ / 64, WCM = NW / WCN;       // waves along N / M
-  constexpr int RB = BM_ / WCM / 32;                  // 32-row blocks per wave (4: 128x64 wave tile, 2: 64x64)
-  constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_IT = BM_ / 8 / NW, B_IT = BN / 8 / NW, LOADS = A_IT + B_IT;
-  constexpr int ST_MIN_ = (RB / 2) * ((EPI == EPI_STORE16 || EPI == EPI_GELU) ? 8 : 16);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int M = g.M, N = g.N, K = g.K;
-  const int lda = g.a_split ? 2 * K : K;
-  const T* __restrict__ A = (const T*)g.A;
-  const T* __restrict__ Bt = (const T*)g.Bt;
-
-  const int G = gridDim.x, b = blockIdx.x;
-  const int tilesN = (N + BN - 1) / BN;
-  const int ntiles = ((M + BM_ - 1) / BM_) * tilesN;
-  const int gq = G >> 3, gr = G & 7, xcd = b & 7;
-  const int b_remap = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (b >> 3);
-  auto tile_mn = [&](int t, int& tm, int& tn) { tm = t / tilesN; tn = t - tm * tilesN; };
-  auto tile_of = [&](int round) -> int {
-    const int base = round * G;
-    return base + ((base + G <= ntiles) ? b_remap : b);
-  };
-
-  // staging: LDS row r = slab*8 + srow with slab = i*NW + wave (parity of the slab index = parity of the wave)
-  const int srow = lane >> 3;
-  const int scol = ((lane & 7) ^ ((4 * (wave & 1) + (srow >> 1)) & 7)) * 8;
-  const T* ap[A_IT];
-  const T* bp[B_IT];
-  auto set_ptrs = [&](int t) {
-    int tm, tn;
-    tile_mn(t, tm, tn);
-    const int m0 = tm * BM_, n0 = tn * BN;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      int ar = m0 + (i * NW + wave) * 8 + srow; ar = ar < M ? ar : M - 1;
-      ap[i] = A + (size_t)ar * lda + scol;
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      int br = n0 + (i * NW + wave) * 8 + srow; br = br < N ? br : N - 1;
-      bp[i] = Bt + (size_t)br * K + scol;
-    }
-  };
-  const int nkb = K / BK, nk = g.a_split ? 2 * nkb : nkb;
-  int lround = 0, lt = tile_of(0), lkt = 0, lslot = 0;
-  if (lt >= ntiles) return;
-  set_ptrs(lt);
-  auto issue = [&]() -> bool {
-    if (lt >= ntiles) return false;
-    char* base = smem + lslot * STAGE;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) glds16(ap[i] + lkt * BK, base + (i * NW + wave) * 1024);
-    const int bk = (lkt >= nkb ? lkt - nkb : lkt) * BK;
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) glds16(bp[i] + bk, base + A_BYTES + (i * NW + wave) * 1024);
-    lslot = lslot + 1 == NS ? 0 : lslot + 1;
-    if (++lkt == nk) {
-      lkt = 0;
-      lt = tile_of(++lround);
-      if (lt < ntiles) set_ptrs(lt);
-    }
-    return true;
-  };
-
-  const int wm = wave / WCN, wn = wave % WCN;
-  const int lr = lane & 31, lh = lane >> 5;
-  const int a_off = (wm * (RB * 32) + lr) * 128;
-  const int b_off = A_BYTES + (wn * 64 + lr) * 128;
-  const int sw = (lr >> 1) & 7;
-  int ck[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) ck[ks] = ((2 * ks + lh) ^ sw) * 16;
-
-  int n_issued = 0, n_done = 0;
-#pragma unroll
-  for (int i = 0; i < NS - 1; ++i) n_issued += issue() ? 1 : 0;
-  auto wait_stage = [&](int younger, bool skip_stores) {
-    if (younger >= 2 && NS >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
-    else if (younger >= 1 && NS >= 3) {
-      if (skip_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + ST_MIN_) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  wait_stage(n_issued - 1, false);
-  __builtin_amdgcn_s_barrier();
-
-  bool stores_pending = false;
-  int slot = 0;
-  int t = tile_of(0);
-  for (int round = 0; t < ntiles; t = tile_of(++round)) {
-    f32x16 acc[RB / 2][2][2];
-#pragma unroll
-    for (int hh = 0; hh < RB / 2; ++hh)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[hh][i][j][e] = 0.f;
-
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool dma_first = (NW == 4) || (NS == 2 && MVLPT_NS2_MODE == 0) || (wave < NW / 2);
-      constexpr bool DMA_MID = NS == 2 && MVLPT_NS2_MODE == 1 && NW != 4;
-      bool issued = false;
-      if (dma_first) issued = issue();
-      const char* base = smem + slot * STAGE;
-      v8 af[2][RB], bf[2][2];
-      auto load_k = [&](int ks, v8 (&a)[RB], v8 (&bb)[2]) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bb[j] = *(const v8*)(base + b_off + j * 4096 + ck[ks]);
-#pragma unroll
-        for (int i = 0; i < RB; ++i) a[i] = *(const v8*)(base + a_off + i * 4096 + ck[ks]);
-      };
-#ifndef MVLPT_G32_DMA_KS
-#define MVLPT_G32_DMA_KS 1
-#endif
-#ifndef MVLPT_G32_NOSCHED
-#define MVLPT_G32_NOSCHED 0
-#endif
-#ifndef MVLPT_G32_PRIO
-#define MVLPT_G32_PRIO 0
-#endif
-#if MVLPT_G32_NOSCHED
-#define G32_SB() do { } while (0)
-#else
-#define G32_SB() __builtin_amdgcn_sched_barrier(0)
-#endif
-      load_k(0, af[0], bf[0]);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int cur = ks & 1;
-        // as in the 16x16 kernel: the prefetch reads of k-step ks+1 sit behind the first MFMA of k-step ks, so hipcc's
-        // lgkmcnt(0) in front of that MFMA does not cover reads that were only just issued
-        G32_SB();
-        acc[0][0][0] = mfma_32x32<T>(bf[cur][0], af[cur][0], acc[0][0][0]);
-        G32_SB();
-        if (ks + 1 < 4) load_k(ks + 1, af[cur ^ 1], bf[cur ^ 1]);
-        G32_SB();
-        if (MVLPT_G32_PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (i == 0 && j == 0) continue;
-            acc[i >> 1][i & 1][j] = mfma_32x32<T>(bf[cur][j], af[cur][i], acc[i >> 1][i & 1][j]);
-          }
-        if (MVLPT_G32_PRIO) __builtin_amdgcn_s_setprio(0);
-        G32_SB();
-        if (DMA_MID && ks == MVLPT_G32_DMA_KS && !dma_first) issued = issue();
-      }
-      if (!DMA_MID && !dma_first) issued = issue();
-      n_issued += issued ? 1 : 0;
-      wait_stage(n_issued - (n_done + 2), stores_pending && NS == 3 && issued);
-      stores_pending = false;
-      ++n_done;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      slot = slot + 1 == NS ? 0 : slot + 1;
-    }
-    int tm, tn;
-    tile_mn(t, tm, tn);
-#pragma unroll
-    for (int hh = 0; hh < RB / 2; ++hh)
-      epilogue_store32<T, EPI>(g, acc[hh], tm * BM_ + wm * (RB * 32) + hh * 64, tn * BN + wn * 64, lane,
-                               LinearRows<144>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE},
-                               LinearRows<144>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE});
-    __builtin_amdgcn_s_barrier();
-    stores_pending = (tm + 1) * BM_ <= M;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------- phased variant
 // 256x128 tile, 8 waves, 3-deep ring, same data movement as above, but every K-stage is cut into FOUR barrier-
 // separated phases  R0 | M0 | R1 | M1  (R = LDS-DMA issue + ds_read of one 32-deep k-step, M = its 16 MFMAs) and waves
@@ -870,22 +569,6 @@ static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hi
   }
   const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
   const int resident = cus * wg_per_cu;
-  // MVLPT_GEMM_MFMA = 16 (default): the 16x16x32 kernel; 32: the v_mfma_f32_32x32x16 main loop.  Measured (round 2, same
-  // pipeline, four scheduling variants): the 32x32x16 form is 10-15 % SLOWER here (8192^3: 1.14 vs 1.30 PF; QKV 220 vs
-  // 194 us) at identical SQ_VALU_MFMA_BUSY_CYCLES, LDS traffic and bank conflicts — SQ_WAIT_INST_ANY (issue stalls behind
-  // the SIMD partner's matrix instructions) grows from 326 M to 455 M quad-cycles: with two waves per SIMD the 32-cycle
-  // instruction halves the interleaving granularity.  Kept as an experiment switch.
-  static const int mfma = getenv("MVLPT_GEMM_MFMA") ? atoi(getenv("MVLPT_GEMM_MFMA")) : 16;
-  if (mfma == 32) {
-    static bool attr32_set = false;
-    if (!attr32_set) {
-      (void)hipFuncSetAttribute((const void*)gemm_bt32_kernel<T, EPI, BM_, BN_, NW, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      attr32_set = true;
-    }
-    hipExtLaunchKernelGGL((gemm_bt32_kernel<T, EPI, BM_, BN_, NW, NS>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), LDS, s,
-                          ea, eb, 0, g);
-    return hipGetLastError();
-  }
   hipExtLaunchKernelGGL((gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), LDS, s,
                         ea, eb, 0, g);
   return hipGetLastError();
@@ -944,8 +627,9 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   }
   // small problems (text tower: M = C*L ~ 7.7k rows) put at most one workgroup on a CU, so nothing hides the
   // LDS-DMA latency of a 2-deep ring: use a 4-deep ring (128 KiB, three K-stages in flight) instead
-  static const int deep = getenv("MVLPT_GEMM_DEEP") ? atoi(getenv("MVLPT_GEMM_DEEP")) : 0;   // text tower alone -7 %, but its 128 KiB
-  // workgroups can no longer share a CU with the image tower kernels they overlap with: whole step +1.4 % -> off
+  static const int deep = getenv("MVLPT_GEMM_DEEP") ? atoi(getenv("MVLPT_GEMM_DEEP")) : 1;   // round 1 (single operands): text tower alone -7 %, overlapped step +1.4 %
+  // (its 128 KiB workgroups cannot share a CU with the image-tower kernels they overlap with) -> off.  Round 2 (split operands
+  // double every K of the text tower): tower alone 5.57 -> 5.10 ms, overlapped step 15.22 -> 15.00 ms -> on.
   const long t_small = (long)((g.M + 127) / 128) * (g.N / 128);
   if (deep && t_small <= num_cus()) {
     *tile_m = 128; *tile_n = 128;

@@ -1,0 +1,46 @@
+"""Stream-concurrency determinism (-m gpu): the two towers of one engine run on different HIP streams in every training
+step (text tower under the image tower).  A tower's result must not depend on what the other stream is doing: the text
+tower forward is repeated while the image tower of the SAME engine runs concurrently and must stay bit-identical to the
+run it made alone (a latent hand-off hazard shows up only under such contention; round 2 found one this way in an
+experimental LayerNorm-folding path, which was not shipped)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("precision", ["split_grad", "fast"])
+def test_text_tower_is_bit_stable_under_a_concurrent_image_tower(precision):
+    from mvlpt_amd.class_prompts import load_class_prompts
+    from mvlpt_amd.config import get_cfg_default
+    from mvlpt_amd.model import CustomCLIP, FrozenCLIP
+    from mvlpt_amd.weights import ARCHS, make_state_dict
+    arch = ARCHS["ViT-B/16"]
+    cfg = get_cfg_default()
+    cfg.TRAINER.MVLPT.COOP.N_CTX = 16
+    pre, C = load_class_prompts("caltech101", 16)
+    torch.manual_seed(0)
+    model = CustomCLIP(cfg, ["c"] * C, FrozenCLIP(make_state_dict(arch, 3), "fp16", precision=precision), pretokenized=pre).cuda()
+    pl, eng = model.prompt_learner, model.engine
+    ctx = pl.ctx.detach()
+    dfeat = torch.randn(C, arch.embed_dim, device="cuda") * 1e-3
+
+    def text(save):
+        f = eng.text_fwd(pl.token_prefix, pl.token_suffix, ctx, pl.layout, pl.eot, save_for_bwd=save).clone()
+        g = eng.text_bwd(dfeat).clone() if save else None
+        return f, g
+
+    side = torch.cuda.Stream()
+    x = torch.randn(64, 3, 224, 224, device="cuda").half()
+    with torch.no_grad():
+        for save in (False, True):
+            f0, g0 = text(save)
+            torch.cuda.synchronize()
+            for it in range(12):
+                with torch.cuda.stream(side):
+                    eng.image_fwd(x)
+                f, g = text(save)
+                torch.cuda.synchronize()
+                assert torch.equal(f, f0), f"text features changed under a concurrent image tower (save={save}, iteration {it})"
+                if save:
+                    assert torch.equal(g, g0), f"context gradient changed under a concurrent image tower (iteration {it})"

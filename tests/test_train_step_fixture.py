@@ -38,7 +38,7 @@ def test_three_reference_train_steps_on_the_oracle_engine():
     z = load_npz("tiny_train_steps")
     tr = _oracle_trainer(z)
     losses, lrs, params = run_three_steps(tr, z, "cpu")
-    check_against_fixture(z, losses, lrs, params, loss_tol=2e-5, delta_tol=2e-4)     # fp32 on both sides
+    check_against_fixture(z, losses, lrs, params, loss_tol=2e-5, delta_tol=5e-4)     # fp32 on both sides (the bound of tests/test_oracle_golden.py: reduction order varies with the thread count)
 
 
 def _reference_style_checkpoint(tmp_path, z, rename_to_upt=False):
