@@ -11,3 +11,4 @@ run --method upt --classes 2191 --steps 6 --warmup 2
 run --method upt --classes 2191 --cut --steps 6 --warmup 2
 run --arch ViT-L/14@336px --method upt --classes 1151 --batch 128 --steps 4 --warmup 2
 run --arch ViT-L/14@336px --method upt --classes 1151 --batch 128 --cut --steps 4 --warmup 2
+run --method upt --classes 2191 --multitask --steps 6 --warmup 2
