@@ -42,27 +42,30 @@ __device__ __forceinline__ void load_own(f32x4 (&reg)[4], const float* row_ptr, 
   for (int t = 0; t < 4; ++t) reg[t] = *(const f32x4*)(row_ptr + 16 * t + 4 * fg);
 }
 // acc[ct][r] = sum_dim C[16ct + (lane&15)][dim] * own[lane&15][dim]   ->  lane holds [own = fr][streamed = 16ct + 4fg + r]
+// (the f32 MFMA issues every 32 cycles but a dependent one only after 40: the four column tiles are four INDEPENDENT
+// accumulator chains, interleaved)
 __device__ __forceinline__ void mm_rows(f32x4 (&acc)[4], const float* lds, const f32x4 (&own)[4], int fr, int fg) {
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 c = *(const f32x4*)(lds + (16 * ct + fr) * RS + 16 * t + 4 * fg);
+  for (int t = 0; t < 4; ++t) {
+    f32x4 c[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) a = mfma32(c[s], own[t][s], a);
-    }
-    acc[ct] = a;
+    for (int ct = 0; ct < 4; ++ct) c[ct] = *(const f32x4*)(lds + (16 * ct + fr) * RS + 16 * t + 4 * fg);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma32(c[ct][s], own[t][s], acc[ct]);
   }
 }
 // out[dt][r'] (own = fr, dim = 16dt + 4fg + r') += sum_streamed p[own][streamed] * C[streamed][dim]
 __device__ __forceinline__ void mm_accum(f32x4 (&out)[4], const float* lds, const f32x4 (&p)[4], int fr, int fg) {
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
+  for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[dt] = mfma32(lds[(16 * ct + 4 * fg + r) * RS + 16 * dt + fr], p[ct][r], out[dt]);
+      for (int dt = 0; dt < 4; ++dt) out[dt] = mfma32(lds[(16 * ct + 4 * fg + r) * RS + 16 * dt + fr], p[ct][r], out[dt]);
 }
 // 16-bit pair store of 4 consecutive values: hi at p, lo at p + lo_off
 template <typename T>
@@ -119,13 +122,13 @@ __global__ __launch_bounds__(256) void attn32_fwd_kernel(Attn32Args a) {
         mx = fmaxf(mx, S[ct][r]);
       }
     const float m_new = fmaxf(m, quad_max32(mx));
-    const float alpha = (m == -INFINITY) ? 0.f : expf(m - m_new);
+    const float alpha = (m == -INFINITY) ? 0.f : __expf(m - m_new);
     float sum = 0.f;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        S[ct][r] = (m_new == -INFINITY) ? 0.f : expf(S[ct][r] - m_new);
+        S[ct][r] = (m_new == -INFINITY) ? 0.f : __expf(S[ct][r] - m_new);
         sum += S[ct][r];
       }
     l = l * alpha + quad_sum32(sum);
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void attn32_dq_kernel(Attn32BwdArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int kk = k0 + 16 * ct + 4 * fg + r;
         const bool ok = kk < L && (!CAUSAL || kk <= q);
-        const float p = ok ? expf(S[ct][r] * SCALE - lse) : 0.f;
+        const float p = ok ? __expf(S[ct][r] * SCALE - lse) : 0.f;
         S[ct][r] = p * (dP[ct][r] - dl);        // dS
       }
     mm_accum(dQ, Ks, S, fr, fg);
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void attn32_dkv_kernel(Attn32BwdArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int j = 16 * ct + 4 * fg + r, qq = q0 + j;
         const bool ok = qq < L && kk < L && (!CAUSAL || kk <= qq);
-        const float p = ok ? expf(S[ct][r] * SCALE - lse_s[j]) : 0.f;
+        const float p = ok ? __expf(S[ct][r] * SCALE - lse_s[j]) : 0.f;
         S[ct][r] = p;
         dP[ct][r] = p * (dP[ct][r] - del_s[j]);   // dS
       }
@@ -276,20 +279,23 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, size_t 
 }
 // one 16-row tile of the streamed side: lane holds [own = fr][streamed = 16*kt + 4fg + r]
 __device__ __forceinline__ f32x4 mm_tile(const float* lds, int kt, const f32x4 (&own)[4], int fr, int fg) {
-  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  f32x4 a[4];                                     // four independent chains (one per 16-wide slice of the head dimension)
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const f32x4 c = *(const f32x4*)(lds + (16 * kt + fr) * RS + 16 * t + 4 * fg);
+  for (int t = 0; t < 4; ++t) a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 c[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) a = mfma32(c[s], own[t][s], a);
-  }
-  return a;
+  for (int t = 0; t < 4; ++t) c[t] = *(const f32x4*)(lds + (16 * kt + fr) * RS + 16 * t + 4 * fg);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = mfma32(c[t][s], own[t][s], a[t]);
+  return (a[0] + a[1]) + (a[2] + a[3]);
 }
 __device__ __forceinline__ void accum_tile(f32x4 (&out)[4], const float* lds, int kt, const f32x4& p, int fr, int fg) {
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
+  for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[dt] = mfma32(lds[(16 * kt + 4 * fg + r) * RS + 16 * dt + fr], p[r], out[dt]);
+    for (int dt = 0; dt < 4; ++dt) out[dt] = mfma32(lds[(16 * kt + 4 * fg + r) * RS + 16 * dt + fr], p[r], out[dt]);
 }
 }  // namespace
 

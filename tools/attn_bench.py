@@ -23,3 +23,14 @@ for (N, L, H, causal) in [(256, 197, 12, False), (256, 205, 12, False), (256, 50
     tb = timeit(lambda: E.op_attention_bwd(qkv, out, dout, lse, N, L, H, causal))
     fl = 4.0 * L * L * 64 * N * H * (0.5 if causal else 1.0)
     print(f"N={N} L={L} H={H} causal={causal}: fwd {tf*1e3:7.1f} us ({fl/tf/1e9:6.1f} TF)  bwd {tb*1e3:7.1f} us ({2.5*fl/tb/1e9:6.1f} TF)")
+
+print("fp32 attention (split-precision mode, f32 MFMA):")
+for (N, L, H, causal) in [(256, 205, 12, False), (100, 77, 8, True), (128, 581, 16, False)]:
+    d = H * 64
+    qkv = torch.randn(N * L, 3 * d, device="cuda")
+    out, lse = E.op_attention32_fwd(qkv, N, L, H, causal)
+    dout = torch.randn(N * L, d, device="cuda")
+    tf = timeit(lambda: E.op_attention32_fwd(qkv, N, L, H, causal))
+    tb = timeit(lambda: E.op_attention32_bwd(qkv, out, dout, lse, N, L, H, causal))
+    fl = 4.0 * L * L * 64 * N * H * (0.5 if causal else 1.0)
+    print(f"N={N} L={L} H={H} causal={causal}: fwd {tf*1e3:7.1f} us ({fl/tf/1e9:6.1f} TF)  bwd {tb*1e3:7.1f} us ({2.5*fl/tb/1e9:6.1f} TF)")
