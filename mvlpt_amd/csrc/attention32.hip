@@ -14,7 +14,8 @@
 // to 68 floats: conflict-free for both access patterns).  Products use swapped operands so that a lane holds
 // S[own row = lane&15][streamed row = 16*ct + 4*(lane>>4) + r]: softmax statistics are lane-local plus two shuffles,
 // and those registers are directly the B operand of the second product (P.V, dS.K, P^T.dO, dS^T.Q) — no LDS round trip.
-#include "kernels.h"
+#include <cstdlib>
+#include "attn_common.h"
 
 namespace mvlpt {
 
@@ -262,6 +263,298 @@ __global__ __launch_bounds__(256) void attn32_dkv_kernel(Attn32BwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 16-bit MFMA, three terms
+// Same three kernels with the products on the 16-bit MFMA (16x the f32-MFMA rate) at ~fp32 accuracy: every fp32 operand is a
+// pair (hi, lo) of 16-bit values and a product keeps the three terms  hi*hi + hi*lo + lo*hi  (the dropped lo*lo is 2^-22
+// of the product), accumulated in fp32.  The streamed side is split ONCE while it is staged (two swizzled 16-bit LDS images,
+// the layout of attention.hip: 128-byte rows, 16-byte chunk c at c ^ (row & 7)); the own rows are split once into
+// registers; P / dS are split in registers right where the fp16 kernels round them.  Transposed operands come from the
+// hardware transpose read (frag_vt), exactly as in the 16-bit kernels.  L = 205: fwd 554 -> see DESIGN.md.
+namespace {
+constexpr int XIMG = CH * 128;          // one 64 x 64 16-bit image
+
+// Staging is split in two so that the NEXT chunk's global loads fly while the current chunk is multiplied:
+// fetch64 (global -> registers: 2 x 8 floats per thread and array) ... compute ... commit64_pair (split + LDS store).
+struct Fetch64 { f32x4 v[4]; };
+__device__ __forceinline__ void fetch64(Fetch64& f, const float* src, size_t ld, int r0, int rows_total, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = i * 256 + tid, r = idx >> 3, c = idx & 7;
+    int row = r0 + r; row = row < rows_total ? row : rows_total - 1;
+    f.v[2 * i] = *(const f32x4*)(src + (size_t)row * ld + c * 8);
+    f.v[2 * i + 1] = *(const f32x4*)(src + (size_t)row * ld + c * 8 + 4);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void commit64_pair(char* hi, char* lo, const Fetch64& f, int tid) {
+  using v8 = typename Vec<T>::v8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = i * 256 + tid, r = idx >> 3, c = idx & 7;
+    v8 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      T x, y;
+      split16<T>(f.v[2 * i][e], x, y); h[e] = x; l[e] = y;
+      split16<T>(f.v[2 * i + 1][e], x, y); h[e + 4] = x; l[e + 4] = y;
+    }
+    const int off = r * 128 + ((c ^ (r & 7)) * 16);
+    *(v8*)(hi + off) = h;
+    *(v8*)(lo + off) = l;
+  }
+}
+// own row as B operands of the 16x16x32 MFMA: dims ks*32 + 8*fg + 0..7, ks = 0, 1
+template <typename T>
+__device__ __forceinline__ void load_own_pair(typename Vec<T>::v8 (&h)[2], typename Vec<T>::v8 (&l)[2], const float* row_ptr, int fg) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const f32x4 a = *(const f32x4*)(row_ptr + ks * 32 + fg * 8), b = *(const f32x4*)(row_ptr + ks * 32 + fg * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      T x, y;
+      split16<T>(a[e], x, y); h[ks][e] = x; l[ks][e] = y;
+      split16<T>(b[e], x, y); h[ks][e + 4] = x; l[ks][e + 4] = y;
+    }
+  }
+}
+// lane holds [own = fr][streamed = 16ct + 4fg + r]
+template <typename T>
+__device__ __forceinline__ void mm_rows3(f32x4 (&acc)[4], const char* hi, const char* lo, const typename Vec<T>::v8 (&oh)[2],
+                                         const typename Vec<T>::v8 (&ol)[2], int fr, int fg) {
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const typename Vec<T>::v8 ah = frag_rows<T>(hi, ct, ks, fr, fg), al = frag_rows<T>(lo, ct, ks, fr, fg);
+      acc[ct] = mfma16<T>(ah, oh[ks], acc[ct]);
+      acc[ct] = mfma16<T>(ah, ol[ks], acc[ct]);
+      acc[ct] = mfma16<T>(al, oh[ks], acc[ct]);
+    }
+}
+// out[dt][r'] (own = fr, dim = 16dt + 4fg + r') += sum_streamed p[own][streamed] * C[streamed][dim]
+template <typename T>
+__device__ __forceinline__ void mm_accum3(f32x4 (&out)[4], const char* hi, const char* lo, const f32x4 (&p)[4], int fr, int fg) {
+  using v8 = typename Vec<T>::v8;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    v8 ph, pl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      T x, y;
+      split16<T>(p[2 * kb][e], x, y); ph[e] = x; pl[e] = y;
+      split16<T>(p[2 * kb + 1][e], x, y); ph[e + 4] = x; pl[e + 4] = y;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const v8 vh = frag_vt<T>(hi, kb, dt, fr, fg), vl = frag_vt<T>(lo, kb, dt, fr, fg);
+      out[dt] = mfma16<T>(vh, ph, out[dt]);
+      out[dt] = mfma16<T>(vh, pl, out[dt]);
+      out[dt] = mfma16<T>(vl, ph, out[dt]);
+    }
+  }
+}
+}  // namespace
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn32x_fwd_kernel(Attn32Args a) {
+  __shared__ __attribute__((aligned(16))) char sm[4 * XIMG];
+  char *Kh = sm, *Kl = sm + XIMG, *Vh = sm + 2 * XIMG, *Vl = sm + 3 * XIMG;
+  using v8 = typename Vec<T>::v8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int n = blockIdx.z, h = blockIdx.y, L = a.L, d = a.H * 64;
+  const size_t ld = 3 * (size_t)d;
+  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
+  const int qb = blockIdx.x * CH, q = qb + wave * 16 + fr;
+  const int qc = q < L ? q : L - 1;
+  v8 Qh[2], Ql[2];
+  load_own_pair<T>(Qh, Ql, base + (size_t)qc * ld, fg);
+  float m = -INFINITY, l = 0.f;
+  f32x4 O[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kend = CAUSAL ? (qb + CH < L ? qb + CH : L) : L;
+  Fetch64 fk, fv;
+  fetch64(fk, base + d, ld, 0, L, tid);
+  fetch64(fv, base + 2 * d, ld, 0, L, tid);
+  for (int k0 = 0; k0 < kend; k0 += CH) {
+    __syncthreads();
+    commit64_pair<T>(Kh, Kl, fk, tid);
+    commit64_pair<T>(Vh, Vl, fv, tid);
+    __syncthreads();
+    if (k0 + CH < kend) {
+      fetch64(fk, base + d, ld, k0 + CH, L, tid);
+      fetch64(fv, base + 2 * d, ld, k0 + CH, L, tid);
+    }
+    f32x4 S[4];
+    mm_rows3<T>(S, Kh, Kl, Qh, Ql, fr, fg);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = k0 + 16 * ct + 4 * fg + r;
+        const bool ok = kk < L && (!CAUSAL || kk <= q);
+        S[ct][r] = ok ? S[ct][r] * SCALE : -INFINITY;
+        mx = fmaxf(mx, S[ct][r]);
+      }
+    const float m_new = fmaxf(m, quad_max32(mx));
+    const float alpha = (m == -INFINITY) ? 0.f : __expf(m - m_new);
+    float sum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        S[ct][r] = (m_new == -INFINITY) ? 0.f : __expf(S[ct][r] - m_new);
+        sum += S[ct][r];
+      }
+    l = l * alpha + quad_sum32(sum);
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) O[i] *= alpha;
+    mm_accum3<T>(O, Vh, Vl, S, fr, fg);
+  }
+  const int qlim = a.q_rows > 0 ? (a.q_rows < L ? a.q_rows : L) : L;
+  if (q < qlim) {
+    const float inv = 1.f / l;
+    T* orow = (T*)a.out_split + ((size_t)n * L + q) * (2 * (size_t)d) + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, d, O[dt] * inv);
+    if (a.lse && fg == 0) a.lse[((size_t)n * a.H + h) * L + q] = m + logf(l);
+  }
+}
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn32x_dq_kernel(Attn32BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) char sm[4 * XIMG];
+  char *Kh = sm, *Kl = sm + XIMG, *Vh = sm + 2 * XIMG, *Vl = sm + 3 * XIMG;
+  using v8 = typename Vec<T>::v8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int n = blockIdx.z, h = blockIdx.y, L = a.L, d = a.H * 64;
+  const size_t ld = 3 * (size_t)d;
+  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
+  const int qb = blockIdx.x * CH, q = qb + wave * 16 + fr;
+  const int qc = q < L ? q : L - 1;
+  const float* grow = a.dout32 + ((size_t)n * L + qc) * d + h * 64;
+  v8 Qh[2], Ql[2], Gh[2], Gl[2];
+  load_own_pair<T>(Qh, Ql, base + (size_t)qc * ld, fg);
+  load_own_pair<T>(Gh, Gl, grow, fg);
+  const size_t stat = ((size_t)n * a.H + h) * L + qc;
+  const float lse = a.lse[stat];
+  float dl = 0.f;      // delta = rowsum(dO * O), fp32 from global
+  {
+    const T* orow = (const T*)a.out_split + ((size_t)n * L + qc) * (2 * (size_t)d) + h * 64;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 o = load_pair4<T>(orow + 16 * t + 4 * fg, d);
+      const f32x4 g = *(const f32x4*)(grow + 16 * t + 4 * fg);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dl += o[e] * g[e];
+    }
+    dl = quad_sum32(dl);
+    if (fg == 0 && q < L) a.delta[stat] = dl;
+  }
+  f32x4 dQ[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dQ[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kend = CAUSAL ? (qb + CH < L ? qb + CH : L) : L;
+  Fetch64 fk, fv;
+  fetch64(fk, base + d, ld, 0, L, tid);
+  fetch64(fv, base + 2 * d, ld, 0, L, tid);
+  for (int k0 = 0; k0 < kend; k0 += CH) {
+    __syncthreads();
+    commit64_pair<T>(Kh, Kl, fk, tid);
+    commit64_pair<T>(Vh, Vl, fv, tid);
+    __syncthreads();
+    if (k0 + CH < kend) {
+      fetch64(fk, base + d, ld, k0 + CH, L, tid);
+      fetch64(fv, base + 2 * d, ld, k0 + CH, L, tid);
+    }
+    f32x4 S[4], dP[4];
+    mm_rows3<T>(S, Kh, Kl, Qh, Ql, fr, fg);
+    mm_rows3<T>(dP, Vh, Vl, Gh, Gl, fr, fg);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = k0 + 16 * ct + 4 * fg + r;
+        const bool ok = kk < L && (!CAUSAL || kk <= q);
+        const float p = ok ? __expf(S[ct][r] * SCALE - lse) : 0.f;
+        S[ct][r] = p * (dP[ct][r] - dl);        // dS
+      }
+    mm_accum3<T>(dQ, Kh, Kl, S, fr, fg);
+  }
+  if (q < L) {
+    T* row = (T*)a.dqkv_split + ((size_t)n * L + q) * (6 * (size_t)d) + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) store_pair4<T>(row + 16 * dt + 4 * fg, 3 * (size_t)d, dQ[dt] * SCALE);
+  }
+}
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn32x_dkv_kernel(Attn32BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) char sm[4 * XIMG];
+  __shared__ float lse_s[CH], del_s[CH];
+  char *Qh = sm, *Ql = sm + XIMG, *Gh = sm + 2 * XIMG, *Gl = sm + 3 * XIMG;
+  using v8 = typename Vec<T>::v8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int n = blockIdx.z, h = blockIdx.y, L = a.L, d = a.H * 64;
+  const size_t ld = 3 * (size_t)d;
+  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
+  const float* dobase = a.dout32 + (size_t)n * L * d + h * 64;
+  const int kb = blockIdx.x * CH, kk = kb + wave * 16 + fr;
+  const int kc = kk < L ? kk : L - 1;
+  v8 Kh[2], Kl[2], Vh[2], Vl[2];
+  load_own_pair<T>(Kh, Kl, base + d + (size_t)kc * ld, fg);
+  load_own_pair<T>(Vh, Vl, base + 2 * d + (size_t)kc * ld, fg);
+  f32x4 dK[4], dV[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dK[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const size_t stat0 = ((size_t)n * a.H + h) * L;
+  Fetch64 fq, fg_;
+  fetch64(fq, base, ld, CAUSAL ? kb : 0, L, tid);
+  fetch64(fg_, dobase, d, CAUSAL ? kb : 0, L, tid);
+  for (int q0 = CAUSAL ? kb : 0; q0 < L; q0 += CH) {
+    __syncthreads();
+    commit64_pair<T>(Qh, Ql, fq, tid);
+    commit64_pair<T>(Gh, Gl, fg_, tid);
+    if (tid < CH) {
+      int qq = q0 + tid; qq = qq < L ? qq : L - 1;
+      lse_s[tid] = a.lse[stat0 + qq];
+      del_s[tid] = a.delta[stat0 + qq];
+    }
+    __syncthreads();
+    if (q0 + CH < L) {
+      fetch64(fq, base, ld, q0 + CH, L, tid);
+      fetch64(fg_, dobase, d, q0 + CH, L, tid);
+    }
+    f32x4 S[4], dP[4];
+    mm_rows3<T>(S, Qh, Ql, Kh, Kl, fr, fg);          // lane: [key = fr][query = q0 + 16ct + 4fg + r]
+    mm_rows3<T>(dP, Gh, Gl, Vh, Vl, fr, fg);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * ct + 4 * fg + r, qq = q0 + j;
+        const bool ok = qq < L && kk < L && (!CAUSAL || kk <= qq);
+        const float p = ok ? __expf(S[ct][r] * SCALE - lse_s[j]) : 0.f;
+        S[ct][r] = p;
+        dP[ct][r] = p * (dP[ct][r] - del_s[j]);   // dS
+      }
+    mm_accum3<T>(dV, Gh, Gl, S, fr, fg);
+    mm_accum3<T>(dK, Qh, Ql, dP, fr, fg);
+  }
+  if (kk < L) {
+    T* row = (T*)a.dqkv_split + ((size_t)n * L + kk) * (6 * (size_t)d) + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      store_pair4<T>(row + d + 16 * dt + 4 * fg, 3 * (size_t)d, dK[dt] * SCALE);
+      store_pair4<T>(row + 2 * d + 16 * dt + 4 * fg, 3 * (size_t)d, dV[dt]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ short sequences
 // L <= 80 (every text sequence: context_length 77; the tiny test towers): ONE workgroup of 5 waves per (sequence, head),
 // wave t owns the 16-row tile t; all of K, V (forward) or Q, K, V, dO (backward) are staged in LDS once, so the whole
@@ -456,9 +749,19 @@ __global__ __launch_bounds__(SNT * 64) void attn32s_bwd_kernel(Attn32BwdArgs a) 
   }
 }
 
+// MVLPT_ATTN32_MODE: 0 = f32 MFMA (exact fp32 products), 1 (default) = three-term products on the 16-bit MFMA;
+// bit 1 (value 2 / 3) additionally routes short sequences (L <= 80) to the generic kernels (experiments)
+static int attn32_mode() {
+  static const int m = getenv("MVLPT_ATTN32_MODE") ? atoi(getenv("MVLPT_ATTN32_MODE")) : 1;
+  return m & 1;
+}
+static bool attn32_short_ok() {
+  static const int m = getenv("MVLPT_ATTN32_MODE") ? atoi(getenv("MVLPT_ATTN32_MODE")) : 1;
+  return (m & 2) == 0;
+}
 template <typename T>
 static hipError_t fwd_t(const Attn32Args& a, hipStream_t s) {
-  if (a.L <= SROWS) {
+  if (a.L <= SROWS && attn32_short_ok()) {
     dim3 grid(a.H, a.N), block(SNT * 64);
     if (a.causal) hipLaunchKernelGGL((attn32s_fwd_kernel<T, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((attn32s_fwd_kernel<T, false>), grid, block, 0, s, a);
@@ -466,25 +769,38 @@ static hipError_t fwd_t(const Attn32Args& a, hipStream_t s) {
   }
   const int lq = a.q_rows > 0 ? (a.q_rows < a.L ? a.q_rows : a.L) : a.L;
   dim3 grid((lq + CH - 1) / CH, a.H, a.N), block(256);
-  if (a.causal) hipLaunchKernelGGL((attn32_fwd_kernel<T, true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((attn32_fwd_kernel<T, false>), grid, block, 0, s, a);
+  if (attn32_mode() == 0) {
+    if (a.causal) hipLaunchKernelGGL((attn32_fwd_kernel<T, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn32_fwd_kernel<T, false>), grid, block, 0, s, a);
+  } else {
+    if (a.causal) hipLaunchKernelGGL((attn32x_fwd_kernel<T, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn32x_fwd_kernel<T, false>), grid, block, 0, s, a);
+  }
   return hipGetLastError();
 }
 template <typename T>
 static hipError_t bwd_t(const Attn32BwdArgs& a, hipStream_t s) {
-  if (a.L <= SROWS) {
+  if (a.L <= SROWS && attn32_short_ok()) {
     dim3 grid(a.H, a.N), block(SNT * 64);
     if (a.causal) hipLaunchKernelGGL((attn32s_bwd_kernel<T, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((attn32s_bwd_kernel<T, false>), grid, block, 0, s, a);
     return hipGetLastError();
   }
   dim3 grid((a.L + CH - 1) / CH, a.H, a.N), block(256);
-  if (a.causal) {
-    hipLaunchKernelGGL((attn32_dq_kernel<T, true>), grid, block, 0, s, a);
-    hipLaunchKernelGGL((attn32_dkv_kernel<T, true>), grid, block, 0, s, a);
+  if (attn32_mode() == 0) {
+    if (a.causal) {
+      hipLaunchKernelGGL((attn32_dq_kernel<T, true>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((attn32_dkv_kernel<T, true>), grid, block, 0, s, a);
+    } else {
+      hipLaunchKernelGGL((attn32_dq_kernel<T, false>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((attn32_dkv_kernel<T, false>), grid, block, 0, s, a);
+    }
+  } else if (a.causal) {
+    hipLaunchKernelGGL((attn32x_dq_kernel<T, true>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((attn32x_dkv_kernel<T, true>), grid, block, 0, s, a);
   } else {
-    hipLaunchKernelGGL((attn32_dq_kernel<T, false>), grid, block, 0, s, a);
-    hipLaunchKernelGGL((attn32_dkv_kernel<T, false>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((attn32x_dq_kernel<T, false>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((attn32x_dkv_kernel<T, false>), grid, block, 0, s, a);
   }
   return hipGetLastError();
 }
