@@ -116,11 +116,11 @@ int mvlpt_op_layernorm_fwd_split(int out_dtype, const float* x, const float* gam
                                  mvlpt_stream_t stream);
 int mvlpt_op_layernorm_bwd_split(int dtype, const void* dy, const float* x, const float* gamma, const float* resid, float* out32,
                                  void* out16, int rows, int d, mvlpt_stream_t stream);
-/* fp32 attention core of the split-precision mode: qkv [N*L,3*H*64] fp32 -> out [N*L, 2*H*64] 16-bit hi|lo pair, lse;
- * backward: dout [N*L,H*64] fp32 -> dqkv [N*L, 6*H*64] 16-bit hi|lo pair (delta: [N*H*L] scratch) */
-int mvlpt_op_attention32_fwd(int dtype, const float* qkv, void* out, float* lse, int N, int L, int H, int causal, int q_rows,
+/* attention core of the split-precision mode; every operand is a 16-bit hi|lo pair [rows, 2*cols] = [hi(cols) | lo(cols)]:
+ * qkv [N*L, 6*H*64] -> out [N*L, 2*H*64], lse;  backward: dout [N*L, 2*H*64] -> dqkv [N*L, 6*H*64] (delta: [N*H*L] scratch) */
+int mvlpt_op_attention32_fwd(int dtype, const void* qkv, void* out, float* lse, int N, int L, int H, int causal, int q_rows,
                              mvlpt_stream_t stream);
-int mvlpt_op_attention32_bwd(int dtype, const float* qkv, const void* out, const float* dout, const float* lse, float* delta,
+int mvlpt_op_attention32_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                              void* dqkv, int N, int L, int H, int causal, mvlpt_stream_t stream);
 int mvlpt_op_layernorm_fwd(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
                            mvlpt_stream_t stream);

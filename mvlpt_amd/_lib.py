@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("MVLPT_HIP_LIB") or os.path.join(_HERE, "libmvlpt_hip.
 
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 LABEL_INT64, LABEL_PROB_F32 = 0, 1
-EPI_STORE16, EPI_GELU, EPI_RESID32, EPI_GELUBWD, EPI_STORE32, EPI_GELU_SPLIT, EPI_GELUBWD_SPLIT = 0, 1, 2, 3, 4, 5, 6
+EPI_STORE16, EPI_GELU, EPI_RESID32, EPI_GELUBWD, EPI_STORE32, EPI_GELU_SPLIT, EPI_GELUBWD_SPLIT, EPI_STORE_SPLIT = 0, 1, 2, 3, 4, 5, 6, 7
 PREC_FAST, PREC_SPLIT_GRAD, PREC_SPLIT_ALL = 0, 1, 2
 
 

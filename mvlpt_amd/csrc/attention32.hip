@@ -1,73 +1,39 @@
-// fp32 multi-head attention (head_dim 64) on the f32-input MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32
-// accumulation, 1/16 of the 16-bit MFMA rate) for the SPLIT-PRECISION mode of the towers that carry a gradient
-// (DESIGN.md "Precision modes").  nn.MultiheadAttention core of clip/model.py:181-183 and its backward.
+// Attention core of the SPLIT-PRECISION mode (head_dim 64) for the towers that carry a gradient (DESIGN.md "Precision
+// modes"): nn.MultiheadAttention core of clip/model.py:181-183 and its backward at ~fp32 accuracy.
 //
 // Why it exists: with 16-bit Q, K, V, P, dO, dS the prompt gradients of a 12-layer tower differ from the reference's
 // fp32 CPU path by 2-4e-3 (every operand rounding contributes ~3e-4); the GEMMs get ~22-bit activations from hi+lo
-// operand pairs (GemmArgs::a_split), and the attention core — 4 % of the FLOPs — simply runs in fp32.
+// operand pairs (GemmArgs::a_split) and so does the attention core.
 //
-// Data flow: qkv32 [N*L, 3d] fp32 (QKV GEMM with the fp32-store epilogue) -> O as a 16-bit hi|lo pair [N*L, 2d] (the
-// split A operand of the out-projection GEMM) + lse;  backward: dO32 [N*L, d] fp32 -> dqkv as a pair [N*L, 6d].
+// Data flow: every activation is a PAIR of 16-bit values, hi = round16(x), lo = round16(x - hi), stored [rows, 2*cols] =
+// [hi(cols) | lo(cols)].  qkv pair [N*L, 6d] (QKV GEMM, EPI_STORE_SPLIT) -> O pair [N*L, 2d] (the split A operand of the
+// out-projection GEMM) + lse;  backward: dO pair [N*L, 2d] -> dqkv pair [N*L, 6d].
 //
-// Structure (all three kernels): a workgroup of 4 waves owns 64 rows (queries, or keys in the dK/dV kernel), 16 per
-// wave, whose two operands stay in registers; the other side is streamed in 64-row chunks through LDS (fp32 rows padded
-// to 68 floats: conflict-free for both access patterns).  Products use swapped operands so that a lane holds
-// S[own row = lane&15][streamed row = 16*ct + 4*(lane>>4) + r]: softmax statistics are lane-local plus two shuffles,
-// and those registers are directly the B operand of the second product (P.V, dS.K, P^T.dO, dS^T.Q) — no LDS round trip.
+// Arithmetic: a product of two pairs keeps the three terms  hi*hi + hi*lo + lo*hi  on the 16-bit MFMA with fp32
+// accumulation (the dropped lo*lo is 2^-22 of the product); softmax, P, dS are fp32 registers that are split in place
+// right where the fast-mode kernels round them.  The short-sequence kernels (text tower) still multiply on the f32 MFMA.
+//
+// Structure of the streamed kernels (fwd, dQ, dK/dV): a workgroup of 4 waves owns 64 rows (queries, or keys in the
+// dK/dV kernel), 16 per wave, whose operands stay in registers; the other side is streamed in 64-row chunks: four
+// swizzled 16-bit LDS images per chunk (hi and lo of two matrices; the layout of attention.hip: 128-byte rows, 16-byte
+// chunk c at c ^ (row & 7)) filled by LDS-DMA straight from the pair tensors — staging costs no VALU work.  Products
+// use swapped operands so that a lane holds S[own row = lane&15][streamed row = 16*ct + 4*(lane>>4) + r]: softmax
+// statistics are lane-local plus two shuffles, and those registers are directly the B operand of the second product
+// (P.V, dS.K, P^T.dO, dS^T.Q) — no LDS round trip.  Transposed operands come from the hardware transpose read (frag_vt).
+// Workgroups of one head run on the same XCD (its K/V stay in that L2).
 #include <cstdlib>
 #include "attn_common.h"
 
 namespace mvlpt {
 
 namespace {
-constexpr int RS = 68;                 // padded LDS row (floats)
+constexpr int RS = 68;                 // padded fp32 LDS row (floats) of the short kernels
 constexpr int CH = 64;                 // streamed chunk / rows per workgroup
+constexpr int XIMG = CH * 128;         // one 64 x 64 16-bit image
 constexpr float SCALE = 0.125f;        // 1/sqrt(64)
 
 __device__ __forceinline__ f32x4 mfma32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ float quad_sum32(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
-__device__ __forceinline__ float quad_max32(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
 
-// rows [r0, r0+64) x 64 floats of a [*, ld] matrix -> LDS (rows >= rows_total re-read the last row: finite, always masked)
-__device__ __forceinline__ void stage64(float* dst, const float* src, size_t ld, int r0, int rows_total, int tid) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = i * 256 + tid, r = idx >> 4, c = (idx & 15) * 4;
-    int row = r0 + r; row = row < rows_total ? row : rows_total - 1;
-    *(f32x4*)(dst + r * RS + c) = *(const f32x4*)(src + (size_t)row * ld + c);
-  }
-}
-// own-row operand fragment: X[row][16t + 4fg + s], t = 0..3 (register-resident for the whole kernel)
-__device__ __forceinline__ void load_own(f32x4 (&reg)[4], const float* row_ptr, int fg) {
-#pragma unroll
-  for (int t = 0; t < 4; ++t) reg[t] = *(const f32x4*)(row_ptr + 16 * t + 4 * fg);
-}
-// acc[ct][r] = sum_dim C[16ct + (lane&15)][dim] * own[lane&15][dim]   ->  lane holds [own = fr][streamed = 16ct + 4fg + r]
-// (the f32 MFMA issues every 32 cycles but a dependent one only after 40: the four column tiles are four INDEPENDENT
-// accumulator chains, interleaved)
-__device__ __forceinline__ void mm_rows(f32x4 (&acc)[4], const float* lds, const f32x4 (&own)[4], int fr, int fg) {
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    f32x4 c[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) c[ct] = *(const f32x4*)(lds + (16 * ct + fr) * RS + 16 * t + 4 * fg);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma32(c[ct][s], own[t][s], acc[ct]);
-  }
-}
-// out[dt][r'] (own = fr, dim = 16dt + 4fg + r') += sum_streamed p[own][streamed] * C[streamed][dim]
-__device__ __forceinline__ void mm_accum(f32x4 (&out)[4], const float* lds, const f32x4 (&p)[4], int fr, int fg) {
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) out[dt] = mfma32(lds[(16 * ct + 4 * fg + r) * RS + 16 * dt + fr], p[ct][r], out[dt]);
-}
 // 16-bit pair store of 4 consecutive values: hi at p, lo at p + lo_off
 template <typename T>
 __device__ __forceinline__ void store_pair4(T* p, size_t lo_off, f32x4 v) {
@@ -82,477 +48,368 @@ __device__ __forceinline__ f32x4 load_pair4(const T* p, size_t lo_off) {
   const typename Vec<T>::v4 hi = *(const typename Vec<T>::v4*)p, lo = *(const typename Vec<T>::v4*)(p + lo_off);
   f32x4 r;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) r[e] = to_f32<T>(hi[e]) + to_f32<T>(lo[e]);
+  for (int e = 0; e < 4; ++e) r[e] = to_f32<T>(hi[e]) + to_f32<T>(lo[e]);      // exact: <= 22 significant bits
   return r;
 }
-}  // namespace
 
-// ------------------------------------------------------------------------------------------------ forward
-template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn32_fwd_kernel(Attn32Args a) {
-  __shared__ __attribute__((aligned(16))) float Ks[CH * RS];
-  __shared__ __attribute__((aligned(16))) float Vs[CH * RS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-  const int n = blockIdx.z, h = blockIdx.y, L = a.L, d = a.H * 64;
-  const size_t ld = 3 * (size_t)d;
-  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
-  const int qb = blockIdx.x * CH, q = qb + wave * 16 + fr;
-  const int qc = q < L ? q : L - 1;
-  f32x4 Q[4];
-  load_own(Q, base + (size_t)qc * ld, fg);
-  float m = -INFINITY, l = 0.f;
-  f32x4 O[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int kend = CAUSAL ? (qb + CH < L ? qb + CH : L) : L;
-  for (int k0 = 0; k0 < kend; k0 += CH) {
-    __syncthreads();
-    stage64(Ks, base + d, ld, k0, L, tid);
-    stage64(Vs, base + 2 * d, ld, k0, L, tid);
-    __syncthreads();
-    f32x4 S[4];
-    mm_rows(S, Ks, Q, fr, fg);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kk = k0 + 16 * ct + 4 * fg + r;
-        const bool ok = kk < L && (!CAUSAL || kk <= q);
-        S[ct][r] = ok ? S[ct][r] * SCALE : -INFINITY;
-        mx = fmaxf(mx, S[ct][r]);
-      }
-    const float m_new = fmaxf(m, quad_max32(mx));
-    const float alpha = (m == -INFINITY) ? 0.f : __expf(m - m_new);
-    float sum = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        S[ct][r] = (m_new == -INFINITY) ? 0.f : __expf(S[ct][r] - m_new);
-        sum += S[ct][r];
-      }
-    l = l * alpha + quad_sum32(sum);
-    m = m_new;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) O[i] *= alpha;
-    mm_accum(O, Vs, S, fr, fg);
-  }
-  const int qlim = a.q_rows > 0 ? (a.q_rows < L ? a.q_rows : L) : L;
-  if (q < qlim) {
-    const float inv = 1.f / l;
-    T* orow = (T*)a.out_split + ((size_t)n * L + q) * (2 * (size_t)d) + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, d, O[dt] * inv);
-    if (a.lse && fg == 0) a.lse[((size_t)n * a.H + h) * L + q] = m + logf(l);
-  }
+// head-chunk workgroup order: consecutive block ids go round-robin over the 8 XCDs, so the chunks of one head take ids
+// that are 8 apart (same XCD, same L2)
+__device__ __forceinline__ bool map_block(int nheads, int nchunks, int& nh, int& ch) {
+  const int b = blockIdx.x, x = b & 7, r = b >> 3;
+  nh = (r / nchunks) * 8 + x;
+  ch = r % nchunks;
+  return nh < nheads;
 }
+static inline int stream_grid(int nheads, int nchunks) { return ((nheads + 7) / 8) * 8 * nchunks; }
 
-// ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
-template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn32_dq_kernel(Attn32BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float Ks[CH * RS];
-  __shared__ __attribute__((aligned(16))) float Vs[CH * RS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-  const int n = blockIdx.z, h = blockIdx.y, L = a.L, d = a.H * 64;
-  const size_t ld = 3 * (size_t)d;
-  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
-  const int qb = blockIdx.x * CH, q = qb + wave * 16 + fr;
-  const int qc = q < L ? q : L - 1;
-  f32x4 Q[4], dO[4];
-  load_own(Q, base + (size_t)qc * ld, fg);
-  load_own(dO, a.dout32 + ((size_t)n * L + qc) * d + h * 64, fg);
-  const size_t stat = ((size_t)n * a.H + h) * L + qc;
-  const float lse = a.lse[stat];
-  // delta = rowsum(dO * O)
-  float dl = 0.f;
-  {
-    const T* orow = (const T*)a.out_split + ((size_t)n * L + qc) * (2 * (size_t)d) + h * 64;
+// DMA rows [r0, r0+64) of a pair matrix into the hi and lo LDS images of a ring slot (8 slabs of 8 rows per image, dealt
+// round-robin to the NW waves; rows past the end re-read the last row: finite, always masked)
+template <typename T, int NW>
+__device__ __forceinline__ void stage_pair(char* hi, char* lo, const T* src, size_t lo_off, size_t ld, int r0, int rows_total,
+                                           int wave, int lane) {
+  const int srow = lane >> 3, chunk = (lane & 7) ^ srow;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 o = load_pair4<T>(orow + 16 * t + 4 * fg, d);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dl += o[e] * dO[t][e];
-    }
-    dl = quad_sum32(dl);
-    if (fg == 0 && q < L) a.delta[stat] = dl;
-  }
-  f32x4 dQ[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) dQ[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int kend = CAUSAL ? (qb + CH < L ? qb + CH : L) : L;
-  for (int k0 = 0; k0 < kend; k0 += CH) {
-    __syncthreads();
-    stage64(Ks, base + d, ld, k0, L, tid);
-    stage64(Vs, base + 2 * d, ld, k0, L, tid);
-    __syncthreads();
-    f32x4 S[4], dP[4];
-    mm_rows(S, Ks, Q, fr, fg);
-    mm_rows(dP, Vs, dO, fr, fg);
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kk = k0 + 16 * ct + 4 * fg + r;
-        const bool ok = kk < L && (!CAUSAL || kk <= q);
-        const float p = ok ? __expf(S[ct][r] * SCALE - lse) : 0.f;
-        S[ct][r] = p * (dP[ct][r] - dl);        // dS
-      }
-    mm_accum(dQ, Ks, S, fr, fg);
-  }
-  if (q < L) {
-    T* row = (T*)a.dqkv_split + ((size_t)n * L + q) * (6 * (size_t)d) + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) store_pair4<T>(row + 16 * dt + 4 * fg, 3 * (size_t)d, dQ[dt] * SCALE);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn32_dkv_kernel(Attn32BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float Qs[CH * RS];
-  __shared__ __attribute__((aligned(16))) float Gs[CH * RS];      // dO chunk
-  __shared__ float lse_s[CH], del_s[CH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-  const int n = blockIdx.z, h = blockIdx.y, L = a.L, d = a.H * 64;
-  const size_t ld = 3 * (size_t)d;
-  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
-  const float* dobase = a.dout32 + (size_t)n * L * d + h * 64;
-  const int kb = blockIdx.x * CH, kk = kb + wave * 16 + fr;
-  const int kc = kk < L ? kk : L - 1;
-  f32x4 K[4], V[4];
-  load_own(K, base + d + (size_t)kc * ld, fg);
-  load_own(V, base + 2 * d + (size_t)kc * ld, fg);
-  f32x4 dK[4], dV[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { dK[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  const size_t stat0 = ((size_t)n * a.H + h) * L;
-  for (int q0 = CAUSAL ? kb : 0; q0 < L; q0 += CH) {
-    __syncthreads();
-    stage64(Qs, base, ld, q0, L, tid);
-    stage64(Gs, dobase, d, q0, L, tid);
-    if (tid < CH) {
-      int qq = q0 + tid; qq = qq < L ? qq : L - 1;
-      lse_s[tid] = a.lse[stat0 + qq];
-      del_s[tid] = a.delta[stat0 + qq];
-    }
-    __syncthreads();
-    f32x4 S[4], dP[4];
-    mm_rows(S, Qs, K, fr, fg);          // lane: [key = fr][query = q0 + 16ct + 4fg + r]
-    mm_rows(dP, Gs, V, fr, fg);
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * ct + 4 * fg + r, qq = q0 + j;
-        const bool ok = qq < L && kk < L && (!CAUSAL || kk <= qq);
-        const float p = ok ? __expf(S[ct][r] * SCALE - lse_s[j]) : 0.f;
-        S[ct][r] = p;
-        dP[ct][r] = p * (dP[ct][r] - del_s[j]);   // dS
-      }
-    mm_accum(dV, Gs, S, fr, fg);
-    mm_accum(dK, Qs, dP, fr, fg);
-  }
-  if (kk < L) {
-    T* row = (T*)a.dqkv_split + ((size_t)n * L + kk) * (6 * (size_t)d) + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      store_pair4<T>(row + d + 16 * dt + 4 * fg, 3 * (size_t)d, dK[dt] * SCALE);
-      store_pair4<T>(row + 2 * d + 16 * dt + 4 * fg, 3 * (size_t)d, dV[dt]);
+  for (int i = 0; i < 8 / NW + (8 % NW ? 1 : 0); ++i) {
+    const int sl = wave + NW * i;
+    if (8 % NW == 0 || sl < 8) {
+      int row = r0 + sl * 8 + srow;
+      row = row < rows_total ? row : rows_total - 1;
+      const T* g = src + (size_t)row * ld + chunk * 8;
+      dma_raw<16>(g, hi + sl * 1024);
+      dma_raw<16>(g + lo_off, lo + sl * 1024);
     }
   }
 }
-
-// ------------------------------------------------------------------------------------------------ 16-bit MFMA, three terms
-// Same three kernels with the products on the 16-bit MFMA (16x the f32-MFMA rate) at ~fp32 accuracy: every fp32 operand is a
-// pair (hi, lo) of 16-bit values and a product keeps the three terms  hi*hi + hi*lo + lo*hi  (the dropped lo*lo is 2^-22
-// of the product), accumulated in fp32.  The streamed side is split ONCE while it is staged (two swizzled 16-bit LDS images,
-// the layout of attention.hip: 128-byte rows, 16-byte chunk c at c ^ (row & 7)); the own rows are split once into
-// registers; P / dS are split in registers right where the fp16 kernels round them.  Transposed operands come from the
-// hardware transpose read (frag_vt), exactly as in the 16-bit kernels.  L = 205: fwd 554 -> see DESIGN.md.
-namespace {
-constexpr int XIMG = CH * 128;          // one 64 x 64 16-bit image
-
-// Staging is split in two so that the NEXT chunk's global loads fly while the current chunk is multiplied:
-// fetch64 (global -> registers: 2 x 8 floats per thread and array) ... compute ... commit64_pair (split + LDS store).
-struct Fetch64 { f32x4 v[4]; };
-__device__ __forceinline__ void fetch64(Fetch64& f, const float* src, size_t ld, int r0, int rows_total, int tid) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = i * 256 + tid, r = idx >> 3, c = idx & 7;
-    int row = r0 + r; row = row < rows_total ? row : rows_total - 1;
-    f.v[2 * i] = *(const f32x4*)(src + (size_t)row * ld + c * 8);
-    f.v[2 * i + 1] = *(const f32x4*)(src + (size_t)row * ld + c * 8 + 4);
-  }
+template <int NW>
+__device__ __forceinline__ void wait_prev_chunk() {       // all but the newest chunk's DMA (4 images x 8 slabs / NW waves) landed
+  if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 }
+// own rows (two 16-row tiles per wave) as B operands of the 16x16x32 MFMA: dims ks*32 + 8*fg + 0..7, ks = 0, 1
 template <typename T>
-__device__ __forceinline__ void commit64_pair(char* hi, char* lo, const Fetch64& f, int tid) {
-  using v8 = typename Vec<T>::v8;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = i * 256 + tid, r = idx >> 3, c = idx & 7;
-    v8 h, l;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      T x, y;
-      split16<T>(f.v[2 * i][e], x, y); h[e] = x; l[e] = y;
-      split16<T>(f.v[2 * i + 1][e], x, y); h[e + 4] = x; l[e + 4] = y;
-    }
-    const int off = r * 128 + ((c ^ (r & 7)) * 16);
-    *(v8*)(hi + off) = h;
-    *(v8*)(lo + off) = l;
-  }
-}
-// own row as B operands of the 16x16x32 MFMA: dims ks*32 + 8*fg + 0..7, ks = 0, 1
-template <typename T>
-__device__ __forceinline__ void load_own_pair(typename Vec<T>::v8 (&h)[2], typename Vec<T>::v8 (&l)[2], const float* row_ptr, int fg) {
+__device__ __forceinline__ void load_own_pair(typename Vec<T>::v8 (&h)[2], typename Vec<T>::v8 (&l)[2], const T* row, size_t lo_off, int fg) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    const f32x4 a = *(const f32x4*)(row_ptr + ks * 32 + fg * 8), b = *(const f32x4*)(row_ptr + ks * 32 + fg * 8 + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      T x, y;
-      split16<T>(a[e], x, y); h[ks][e] = x; l[ks][e] = y;
-      split16<T>(b[e], x, y); h[ks][e + 4] = x; l[ks][e + 4] = y;
-    }
+    h[ks] = *(const typename Vec<T>::v8*)(row + ks * 32 + fg * 8);
+    l[ks] = *(const typename Vec<T>::v8*)(row + lo_off + ks * 32 + fg * 8);
   }
 }
-// lane holds [own = fr][streamed = 16ct + 4fg + r]
+// acc[t][ct]: lane holds [own row = tile t, fr][streamed = 16ct + 4fg + r]; every LDS fragment feeds both own tiles
 template <typename T>
-__device__ __forceinline__ void mm_rows3(f32x4 (&acc)[4], const char* hi, const char* lo, const typename Vec<T>::v8 (&oh)[2],
-                                         const typename Vec<T>::v8 (&ol)[2], int fr, int fg) {
+__device__ __forceinline__ void mm_rows3(f32x4 (&acc)[2][4], const char* hi, const char* lo, const typename Vec<T>::v8 (&oh)[2][2],
+                                         const typename Vec<T>::v8 (&ol)[2][2], int fr, int fg) {
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       const typename Vec<T>::v8 ah = frag_rows<T>(hi, ct, ks, fr, fg), al = frag_rows<T>(lo, ct, ks, fr, fg);
-      acc[ct] = mfma16<T>(ah, oh[ks], acc[ct]);
-      acc[ct] = mfma16<T>(ah, ol[ks], acc[ct]);
-      acc[ct] = mfma16<T>(al, oh[ks], acc[ct]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t][ct] = mfma16<T>(ah, oh[t][ks], acc[t][ct]);
+        acc[t][ct] = mfma16<T>(ah, ol[t][ks], acc[t][ct]);
+        acc[t][ct] = mfma16<T>(al, oh[t][ks], acc[t][ct]);
+      }
     }
 }
-// out[dt][r'] (own = fr, dim = 16dt + 4fg + r') += sum_streamed p[own][streamed] * C[streamed][dim]
+// out[t][dt][r'] (own = tile t, fr; dim = 16dt + 4fg + r') += sum_streamed p[t][own][streamed] * C[streamed][dim]
 template <typename T>
-__device__ __forceinline__ void mm_accum3(f32x4 (&out)[4], const char* hi, const char* lo, const f32x4 (&p)[4], int fr, int fg) {
+__device__ __forceinline__ void mm_accum3(f32x4 (&out)[2][4], const char* hi, const char* lo, const f32x4 (&p)[2][4], int fr, int fg) {
   using v8 = typename Vec<T>::v8;
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-    v8 ph, pl;
+    v8 ph[2], pl[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      T x, y;
-      split16<T>(p[2 * kb][e], x, y); ph[e] = x; pl[e] = y;
-      split16<T>(p[2 * kb + 1][e], x, y); ph[e + 4] = x; pl[e + 4] = y;
-    }
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        T x, y;
+        split16<T>(p[t][2 * kb][e], x, y); ph[t][e] = x; pl[t][e] = y;
+        split16<T>(p[t][2 * kb + 1][e], x, y); ph[t][e + 4] = x; pl[t][e + 4] = y;
+      }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const v8 vh = frag_vt<T>(hi, kb, dt, fr, fg), vl = frag_vt<T>(lo, kb, dt, fr, fg);
-      out[dt] = mfma16<T>(vh, ph, out[dt]);
-      out[dt] = mfma16<T>(vh, pl, out[dt]);
-      out[dt] = mfma16<T>(vl, ph, out[dt]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        out[t][dt] = mfma16<T>(vh, ph[t], out[t][dt]);
+        out[t][dt] = mfma16<T>(vh, pl[t], out[t][dt]);
+        out[t][dt] = mfma16<T>(vl, ph[t], out[t][dt]);
+      }
     }
   }
 }
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float SC2 = SCALE * LOG2E;      // exp(s/8 - m/8) = exp2(s*SC2 - m*SC2)
 }  // namespace
 
-template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn32x_fwd_kernel(Attn32Args a) {
-  __shared__ __attribute__((aligned(16))) char sm[4 * XIMG];
-  char *Kh = sm, *Kl = sm + XIMG, *Vh = sm + 2 * XIMG, *Vl = sm + 3 * XIMG;
+// ------------------------------------------------------------------------------------------------ streamed kernels
+// NW waves x 32 own rows; ring of two slots x four 8 KiB images (64 KiB): chunk c+1 is in flight while chunk c is multiplied
+template <typename T, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void attn32x_fwd_kernel(Attn32Args a, int nqc) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
   using v8 = typename Vec<T>::v8;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-  const int n = blockIdx.z, h = blockIdx.y, L = a.L, d = a.H * 64;
-  const size_t ld = 3 * (size_t)d;
-  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
-  const int qb = blockIdx.x * CH, q = qb + wave * 16 + fr;
-  const int qc = q < L ? q : L - 1;
-  v8 Qh[2], Ql[2];
-  load_own_pair<T>(Qh, Ql, base + (size_t)qc * ld, fg);
-  float m = -INFINITY, l = 0.f;
-  f32x4 O[4];
+  constexpr int WR = NW * 32;
+  int nh, qcx;
+  if (!map_block(a.N * a.H, nqc, nh, qcx)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+  const int n = nh / a.H, h = nh % a.H, L = a.L, d = a.H * 64;
+  const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d;
+  const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
+  const int qb = qcx * WR;
+  const int kend = CAUSAL ? (qb + WR < L ? qb + WR : L) : L;
+  const int nch = (kend + CH - 1) / CH;
+  auto issue = [&](int c) {
+    char* buf = sm + (c & 1) * 4 * XIMG;
+    stage_pair<T, NW>(buf, buf + XIMG, base + d, lo, ld, c * CH, L, wave, lane);
+    stage_pair<T, NW>(buf + 2 * XIMG, buf + 3 * XIMG, base + 2 * d, lo, ld, c * CH, L, wave, lane);
+  };
+  issue(0);
+  int q[2];
+  v8 Qh[2][2], Ql[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int kend = CAUSAL ? (qb + CH < L ? qb + CH : L) : L;
-  Fetch64 fk, fv;
-  fetch64(fk, base + d, ld, 0, L, tid);
-  fetch64(fv, base + 2 * d, ld, 0, L, tid);
-  for (int k0 = 0; k0 < kend; k0 += CH) {
-    __syncthreads();
-    commit64_pair<T>(Kh, Kl, fk, tid);
-    commit64_pair<T>(Vh, Vl, fv, tid);
-    __syncthreads();
-    if (k0 + CH < kend) {
-      fetch64(fk, base + d, ld, k0 + CH, L, tid);
-      fetch64(fv, base + 2 * d, ld, k0 + CH, L, tid);
+  for (int t = 0; t < 2; ++t) {
+    q[t] = qb + wave * 32 + t * 16 + fr;
+    load_own_pair<T>(Qh[t], Ql[t], base + (size_t)(q[t] < L ? q[t] : L - 1) * ld, lo, fg);
+  }
+  // the compiler's own wait for these loads sits here, not inside the loop (it does not see the asm-issued DMA)
+  asm volatile("" ::"v"(Qh[0][0]), "v"(Qh[0][1]), "v"(Qh[1][0]), "v"(Qh[1][1]), "v"(Ql[0][0]), "v"(Ql[0][1]), "v"(Ql[1][0]), "v"(Ql[1][1]));
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};      // m in raw-score units; l is this lane's share of the row sum
+  f32x4 O[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) O[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < nch; ++c) {
+    if (c > 0) __builtin_amdgcn_s_barrier();                    // every wave is done with the slot chunk c+1 overwrites
+    if (c + 1 < nch) { issue(c + 1); wait_prev_chunk<NW>(); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // all pieces of chunk c have landed
+    const char* Kh = sm + (c & 1) * 4 * XIMG;
+    const int k0 = c * CH;
+    f32x4 S[2][4];
+    mm_rows3<T>(S, Kh, Kh + XIMG, Qh, Ql, fr, fg);
+    const bool edge = CAUSAL || k0 + CH > L;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (edge) {
+            const int kk = k0 + 16 * ct + 4 * fg + r;
+            if (!(kk < L && (!CAUSAL || kk <= q[t]))) S[t][ct][r] = -INFINITY;
+          }
+          mx = fmaxf(mx, S[t][ct][r]);
+        }
+      const float m_new = fmaxf(m[t], quad_max(mx));            // finite from chunk 0 on (key 0 is never masked)
+      const float alpha = __builtin_amdgcn_exp2f((m[t] - m_new) * SC2), msc = m_new * SC2;
+      m[t] = m_new;
+      float sum = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          S[t][ct][r] = __builtin_amdgcn_exp2f(fmaf(S[t][ct][r], SC2, -msc));
+          sum += S[t][ct][r];
+        }
+      l[t] = l[t] * alpha + sum;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) O[t][i] *= alpha;
     }
-    f32x4 S[4];
-    mm_rows3<T>(S, Kh, Kl, Qh, Ql, fr, fg);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kk = k0 + 16 * ct + 4 * fg + r;
-        const bool ok = kk < L && (!CAUSAL || kk <= q);
-        S[ct][r] = ok ? S[ct][r] * SCALE : -INFINITY;
-        mx = fmaxf(mx, S[ct][r]);
-      }
-    const float m_new = fmaxf(m, quad_max32(mx));
-    const float alpha = (m == -INFINITY) ? 0.f : __expf(m - m_new);
-    float sum = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        S[ct][r] = (m_new == -INFINITY) ? 0.f : __expf(S[ct][r] - m_new);
-        sum += S[ct][r];
-      }
-    l = l * alpha + quad_sum32(sum);
-    m = m_new;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) O[i] *= alpha;
-    mm_accum3<T>(O, Vh, Vl, S, fr, fg);
+    mm_accum3<T>(O, Kh + 2 * XIMG, Kh + 3 * XIMG, S, fr, fg);
   }
   const int qlim = a.q_rows > 0 ? (a.q_rows < L ? a.q_rows : L) : L;
-  if (q < qlim) {
-    const float inv = 1.f / l;
-    T* orow = (T*)a.out_split + ((size_t)n * L + q) * (2 * (size_t)d) + h * 64;
+  // rows that are not computed get lse = +huge: a backward over the full sequence then sees P = 0 there (finite), not garbage
+  if (a.lse && qlim < L && qcx == 0)
+    for (int j = qlim + tid; j < L; j += NW * 64) a.lse[((size_t)n * a.H + h) * L + j] = 3.0e38f;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, d, O[dt] * inv);
-    if (a.lse && fg == 0) a.lse[((size_t)n * a.H + h) * L + q] = m + logf(l);
+  for (int t = 0; t < 2; ++t) {
+    const float lt = quad_sum(l[t]);
+    if (q[t] < qlim) {
+      const float inv = 1.f / lt;
+      T* orow = (T*)a.out_split + ((size_t)n * L + q[t]) * (2 * (size_t)d) + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, d, O[t][dt] * inv);
+      if (a.lse && fg == 0) a.lse[((size_t)n * a.H + h) * L + q[t]] = m[t] * SCALE + logf(lt);
+    }
   }
 }
 
-template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn32x_dq_kernel(Attn32BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) char sm[4 * XIMG];
-  char *Kh = sm, *Kl = sm + XIMG, *Vh = sm + 2 * XIMG, *Vl = sm + 3 * XIMG;
+template <typename T, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void attn32x_dq_kernel(Attn32BwdArgs a, int nqc) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
   using v8 = typename Vec<T>::v8;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-  const int n = blockIdx.z, h = blockIdx.y, L = a.L, d = a.H * 64;
-  const size_t ld = 3 * (size_t)d;
-  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
-  const int qb = blockIdx.x * CH, q = qb + wave * 16 + fr;
-  const int qc = q < L ? q : L - 1;
-  const float* grow = a.dout32 + ((size_t)n * L + qc) * d + h * 64;
-  v8 Qh[2], Ql[2], Gh[2], Gl[2];
-  load_own_pair<T>(Qh, Ql, base + (size_t)qc * ld, fg);
-  load_own_pair<T>(Gh, Gl, grow, fg);
-  const size_t stat = ((size_t)n * a.H + h) * L + qc;
-  const float lse = a.lse[stat];
-  float dl = 0.f;      // delta = rowsum(dO * O), fp32 from global
-  {
+  constexpr int WR = NW * 32;
+  int nh, qcx;
+  if (!map_block(a.N * a.H, nqc, nh, qcx)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+  const int n = nh / a.H, h = nh % a.H, L = a.L, d = a.H * 64;
+  const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d;
+  const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
+  const int qb = qcx * WR;
+  const int kend = CAUSAL ? (qb + WR < L ? qb + WR : L) : L;
+  const int nch = (kend + CH - 1) / CH;
+  auto issue = [&](int c) {
+    char* buf = sm + (c & 1) * 4 * XIMG;
+    stage_pair<T, NW>(buf, buf + XIMG, base + d, lo, ld, c * CH, L, wave, lane);
+    stage_pair<T, NW>(buf + 2 * XIMG, buf + 3 * XIMG, base + 2 * d, lo, ld, c * CH, L, wave, lane);
+  };
+  issue(0);
+  int q[2];
+  v8 Qh[2][2], Ql[2][2], Gh[2][2], Gl[2][2];
+  float nlse[2], dl[2];       // -lse * log2(e);  delta = rowsum(dO * O)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    q[t] = qb + wave * 32 + t * 16 + fr;
+    const int qc = q[t] < L ? q[t] : L - 1;
+    const T* grow = (const T*)a.dout_split + ((size_t)n * L + qc) * (2 * (size_t)d) + h * 64;
     const T* orow = (const T*)a.out_split + ((size_t)n * L + qc) * (2 * (size_t)d) + h * 64;
+    load_own_pair<T>(Qh[t], Ql[t], base + (size_t)qc * ld, lo, fg);
+    load_own_pair<T>(Gh[t], Gl[t], grow, d, fg);
+    const size_t stat = ((size_t)n * a.H + h) * L + qc;
+    nlse[t] = -a.lse[stat] * LOG2E;
+    float acc = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 o = load_pair4<T>(orow + 16 * t + 4 * fg, d);
-      const f32x4 g = *(const f32x4*)(grow + 16 * t + 4 * fg);
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 o = load_pair4<T>(orow + 16 * k + 4 * fg, d);
+      const f32x4 g = load_pair4<T>(grow + 16 * k + 4 * fg, d);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dl += o[e] * g[e];
+      for (int e = 0; e < 4; ++e) acc += o[e] * g[e];
     }
-    dl = quad_sum32(dl);
-    if (fg == 0 && q < L) a.delta[stat] = dl;
+    dl[t] = quad_sum(acc);
+    if (fg == 0 && q[t] < L) a.delta[stat] = dl[t];
   }
-  f32x4 dQ[4];
+  asm volatile("" ::"v"(Qh[0][0]), "v"(Qh[0][1]), "v"(Qh[1][0]), "v"(Qh[1][1]), "v"(Ql[0][0]), "v"(Ql[0][1]), "v"(Ql[1][0]), "v"(Ql[1][1]));
+  asm volatile("" ::"v"(Gh[0][0]), "v"(Gh[0][1]), "v"(Gh[1][0]), "v"(Gh[1][1]), "v"(Gl[0][0]), "v"(Gl[0][1]), "v"(Gl[1][0]), "v"(Gl[1][1]));
+  f32x4 dQ[2][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dQ[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int kend = CAUSAL ? (qb + CH < L ? qb + CH : L) : L;
-  Fetch64 fk, fv;
-  fetch64(fk, base + d, ld, 0, L, tid);
-  fetch64(fv, base + 2 * d, ld, 0, L, tid);
-  for (int k0 = 0; k0 < kend; k0 += CH) {
-    __syncthreads();
-    commit64_pair<T>(Kh, Kl, fk, tid);
-    commit64_pair<T>(Vh, Vl, fv, tid);
-    __syncthreads();
-    if (k0 + CH < kend) {
-      fetch64(fk, base + d, ld, k0 + CH, L, tid);
-      fetch64(fv, base + 2 * d, ld, k0 + CH, L, tid);
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dQ[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < nch; ++c) {
+    if (c > 0) __builtin_amdgcn_s_barrier();
+    if (c + 1 < nch) { issue(c + 1); wait_prev_chunk<NW>(); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* Kh = sm + (c & 1) * 4 * XIMG;
+    const int k0 = c * CH;
+    f32x4 S[2][4], dP[2][4];
+    mm_rows3<T>(S, Kh, Kh + XIMG, Qh, Ql, fr, fg);
+    mm_rows3<T>(dP, Kh + 2 * XIMG, Kh + 3 * XIMG, Gh, Gl, fr, fg);
+    const bool edge = CAUSAL || k0 + CH > L;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = __builtin_amdgcn_exp2f(fmaf(S[t][ct][r], SC2, nlse[t]));
+          if (edge) {
+            const int kk = k0 + 16 * ct + 4 * fg + r;
+            if (!(kk < L && (!CAUSAL || kk <= q[t]))) p = 0.f;
+          }
+          S[t][ct][r] = p * (dP[t][ct][r] - dl[t]);        // dS
+        }
+    mm_accum3<T>(dQ, Kh, Kh + XIMG, S, fr, fg);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    if (q[t] < L) {
+      T* row = (T*)a.dqkv_split + ((size_t)n * L + q[t]) * ld + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store_pair4<T>(row + 16 * dt + 4 * fg, lo, dQ[t][dt] * SCALE);
     }
-    f32x4 S[4], dP[4];
-    mm_rows3<T>(S, Kh, Kl, Qh, Ql, fr, fg);
-    mm_rows3<T>(dP, Vh, Vl, Gh, Gl, fr, fg);
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kk = k0 + 16 * ct + 4 * fg + r;
-        const bool ok = kk < L && (!CAUSAL || kk <= q);
-        const float p = ok ? __expf(S[ct][r] * SCALE - lse) : 0.f;
-        S[ct][r] = p * (dP[ct][r] - dl);        // dS
-      }
-    mm_accum3<T>(dQ, Kh, Kl, S, fr, fg);
-  }
-  if (q < L) {
-    T* row = (T*)a.dqkv_split + ((size_t)n * L + q) * (6 * (size_t)d) + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) store_pair4<T>(row + 16 * dt + 4 * fg, 3 * (size_t)d, dQ[dt] * SCALE);
-  }
 }
 
-template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn32x_dkv_kernel(Attn32BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) char sm[4 * XIMG];
-  __shared__ float lse_s[CH], del_s[CH];
-  char *Qh = sm, *Ql = sm + XIMG, *Gh = sm + 2 * XIMG, *Gl = sm + 3 * XIMG;
+template <typename T, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void attn32x_dkv_kernel(Attn32BwdArgs a, int nkc, int lpad) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
   using v8 = typename Vec<T>::v8;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-  const int n = blockIdx.z, h = blockIdx.y, L = a.L, d = a.H * 64;
-  const size_t ld = 3 * (size_t)d;
-  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
-  const float* dobase = a.dout32 + (size_t)n * L * d + h * 64;
-  const int kb = blockIdx.x * CH, kk = kb + wave * 16 + fr;
-  const int kc = kk < L ? kk : L - 1;
-  v8 Kh[2], Kl[2], Vh[2], Vl[2];
-  load_own_pair<T>(Kh, Kl, base + d + (size_t)kc * ld, fg);
-  load_own_pair<T>(Vh, Vl, base + 2 * d + (size_t)kc * ld, fg);
-  f32x4 dK[4], dV[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { dK[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  constexpr int WR = NW * 32;
+  float* nlse_s = (float*)(sm + 8 * XIMG);      // [lpad] -lse * log2(e)
+  float* del_s = nlse_s + lpad;                 // [lpad]
+  int nh, kcx;
+  if (!map_block(a.N * a.H, nkc, nh, kcx)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+  const int n = nh / a.H, h = nh % a.H, L = a.L, d = a.H * 64;
+  const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d, gld = 2 * (size_t)d;
+  const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
+  const T* gbase = (const T*)a.dout_split + (size_t)n * L * gld + h * 64;
+  const int kb = kcx * WR;
+  const int c0 = CAUSAL ? kb / CH : 0, nch = (L + CH - 1) / CH;     // causal: queries before the first own key see none of them
+  auto issue = [&](int c) {
+    char* buf = sm + (c & 1) * 4 * XIMG;
+    stage_pair<T, NW>(buf, buf + XIMG, base, lo, ld, c * CH, L, wave, lane);
+    stage_pair<T, NW>(buf + 2 * XIMG, buf + 3 * XIMG, gbase, d, gld, c * CH, L, wave, lane);
+  };
+  issue(c0);
   const size_t stat0 = ((size_t)n * a.H + h) * L;
-  Fetch64 fq, fg_;
-  fetch64(fq, base, ld, CAUSAL ? kb : 0, L, tid);
-  fetch64(fg_, dobase, d, CAUSAL ? kb : 0, L, tid);
-  for (int q0 = CAUSAL ? kb : 0; q0 < L; q0 += CH) {
-    __syncthreads();
-    commit64_pair<T>(Qh, Ql, fq, tid);
-    commit64_pair<T>(Gh, Gl, fg_, tid);
-    if (tid < CH) {
-      int qq = q0 + tid; qq = qq < L ? qq : L - 1;
-      lse_s[tid] = a.lse[stat0 + qq];
-      del_s[tid] = a.delta[stat0 + qq];
-    }
-    __syncthreads();
-    if (q0 + CH < L) {
-      fetch64(fq, base, ld, q0 + CH, L, tid);
-      fetch64(fg_, dobase, d, q0 + CH, L, tid);
-    }
-    f32x4 S[4], dP[4];
-    mm_rows3<T>(S, Qh, Ql, Kh, Kl, fr, fg);          // lane: [key = fr][query = q0 + 16ct + 4fg + r]
-    mm_rows3<T>(dP, Gh, Gl, Vh, Vl, fr, fg);
+  for (int j = tid; j < lpad; j += NW * 64) {
+    const int jj = j < L ? j : L - 1;
+    nlse_s[j] = -a.lse[stat0 + jj] * LOG2E;
+    del_s[j] = a.delta[stat0 + jj];
+  }
+  int kk[2];
+  v8 Kh[2][2], Kl[2][2], Vh[2][2], Vl[2][2];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+  for (int t = 0; t < 2; ++t) {
+    kk[t] = kb + wave * 32 + t * 16 + fr;
+    const int kc = kk[t] < L ? kk[t] : L - 1;
+    load_own_pair<T>(Kh[t], Kl[t], base + d + (size_t)kc * ld, lo, fg);
+    load_own_pair<T>(Vh[t], Vl[t], base + 2 * d + (size_t)kc * ld, lo, fg);
+  }
+  asm volatile("" ::"v"(Kh[0][0]), "v"(Kh[0][1]), "v"(Kh[1][0]), "v"(Kh[1][1]), "v"(Kl[0][0]), "v"(Kl[0][1]), "v"(Kl[1][0]), "v"(Kl[1][1]));
+  asm volatile("" ::"v"(Vh[0][0]), "v"(Vh[0][1]), "v"(Vh[1][0]), "v"(Vh[1][1]), "v"(Vl[0][0]), "v"(Vl[0][1]), "v"(Vl[1][0]), "v"(Vl[1][1]));
+  f32x4 dK[2][4], dV[2][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * ct + 4 * fg + r, qq = q0 + j;
-        const bool ok = qq < L && kk < L && (!CAUSAL || kk <= qq);
-        const float p = ok ? __expf(S[ct][r] * SCALE - lse_s[j]) : 0.f;
-        S[ct][r] = p;
-        dP[ct][r] = p * (dP[ct][r] - del_s[j]);   // dS
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dK[t][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[t][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int c = c0; c < nch; ++c) {
+    if (c > c0) __builtin_amdgcn_s_barrier();
+    if (c + 1 < nch) { issue(c + 1); wait_prev_chunk<NW>(); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // (also publishes nlse_s / del_s the first time round)
+    const char* Qh = sm + (c & 1) * 4 * XIMG;
+    const int q0 = c * CH;
+    f32x4 S[2][4], dP[2][4];
+    mm_rows3<T>(S, Qh, Qh + XIMG, Kh, Kl, fr, fg);          // lane: [key = tile t, fr][query = q0 + 16ct + 4fg + r]
+    mm_rows3<T>(dP, Qh + 2 * XIMG, Qh + 3 * XIMG, Vh, Vl, fr, fg);
+    const bool edge = CAUSAL || q0 + CH > L;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const f32x4 nl = *(const f32x4*)(nlse_s + q0 + 16 * ct + 4 * fg), de = *(const f32x4*)(del_s + q0 + 16 * ct + 4 * fg);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = __builtin_amdgcn_exp2f(fmaf(S[t][ct][r], SC2, nl[r]));
+          if (edge) {
+            const int qq = q0 + 16 * ct + 4 * fg + r;
+            if (!(qq < L && (!CAUSAL || kk[t] <= qq))) p = 0.f;
+          }
+          S[t][ct][r] = p;
+          dP[t][ct][r] = p * (dP[t][ct][r] - de[r]);   // dS
+        }
+    }
+    mm_accum3<T>(dV, Qh + 2 * XIMG, Qh + 3 * XIMG, S, fr, fg);
+    mm_accum3<T>(dK, Qh, Qh + XIMG, dP, fr, fg);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    if (kk[t] < L) {
+      T* row = (T*)a.dqkv_split + ((size_t)n * L + kk[t]) * ld + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        store_pair4<T>(row + d + 16 * dt + 4 * fg, lo, dK[t][dt] * SCALE);
+        store_pair4<T>(row + 2 * d + 16 * dt + 4 * fg, lo, dV[t][dt]);
       }
-    mm_accum3<T>(dV, Gh, Gl, S, fr, fg);
-    mm_accum3<T>(dK, Qh, Ql, dP, fr, fg);
-  }
-  if (kk < L) {
-    T* row = (T*)a.dqkv_split + ((size_t)n * L + kk) * (6 * (size_t)d) + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      store_pair4<T>(row + d + 16 * dt + 4 * fg, 3 * (size_t)d, dK[dt] * SCALE);
-      store_pair4<T>(row + 2 * d + 16 * dt + 4 * fg, 3 * (size_t)d, dV[dt]);
     }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ short sequences
@@ -563,12 +420,24 @@ __global__ __launch_bounds__(256) void attn32x_dkv_kernel(Attn32BwdArgs a) {
 namespace {
 constexpr int SNT = 5, SROWS = SNT * 16;           // tiles / padded rows
 
-__device__ __forceinline__ void stage_rows(float* dst, const float* src, size_t ld, int L, int tid, int nthreads) {
+// pair rows -> fp32 LDS rows (hi + lo is exact in fp32)
+template <typename T>
+__device__ __forceinline__ void stage_rows(float* dst, const T* src, size_t lo_off, size_t ld, int L, int tid, int nthreads) {
   for (int idx = tid; idx < SROWS * 16; idx += nthreads) {
     const int r = idx >> 4, c = (idx & 15) * 4;
     const int row = r < L ? r : L - 1;
-    *(f32x4*)(dst + r * RS + c) = *(const f32x4*)(src + (size_t)row * ld + c);
+    *(f32x4*)(dst + r * RS + c) = load_pair4<T>(src + (size_t)row * ld + c, lo_off);
   }
+}
+// own-row operand fragment: X[row][16t + 4fg + s], t = 0..3 (register-resident for the whole kernel)
+template <typename T>
+__device__ __forceinline__ void load_own(f32x4 (&reg)[4], const T* row_ptr, size_t lo_off, int fg) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) reg[t] = load_pair4<T>(row_ptr + 16 * t + 4 * fg, lo_off);
+}
+__device__ __forceinline__ void load_own_lds(f32x4 (&reg)[4], const float* row_ptr, int fg) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) reg[t] = *(const f32x4*)(row_ptr + 16 * t + 4 * fg);
 }
 // one 16-row tile of the streamed side: lane holds [own = fr][streamed = 16*kt + 4fg + r]
 __device__ __forceinline__ f32x4 mm_tile(const float* lds, int kt, const f32x4 (&own)[4], int fr, int fg) {
@@ -598,16 +467,18 @@ __global__ __launch_bounds__(SNT * 64) void attn32s_fwd_kernel(Attn32Args a) {
   __shared__ __attribute__((aligned(16))) float Vs[SROWS * RS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
   const int n = blockIdx.y, h = blockIdx.x, L = a.L, d = a.H * 64;
-  const size_t ld = 3 * (size_t)d;
-  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
-  stage_rows(Ks, base + d, ld, L, tid, SNT * 64);
-  stage_rows(Vs, base + 2 * d, ld, L, tid, SNT * 64);
+  const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d;
+  const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
+  stage_rows<T>(Ks, base + d, lo, ld, L, tid, SNT * 64);
+  stage_rows<T>(Vs, base + 2 * d, lo, ld, L, tid, SNT * 64);
   const int nt = (L + 15) >> 4;
   const int qlim = a.q_rows > 0 ? (a.q_rows < L ? a.q_rows : L) : L;
   const int q = wave * 16 + fr, qc = q < L ? q : L - 1;
   f32x4 Q[4];
-  load_own(Q, base + (size_t)qc * ld, fg);
+  load_own<T>(Q, base + (size_t)qc * ld, lo, fg);
   __syncthreads();
+  if (a.lse && qlim < L)          // rows that are not computed: lse = +huge (P = 0 in a backward over the full sequence)
+    for (int j = qlim + tid; j < L; j += SNT * 64) a.lse[((size_t)n * a.H + h) * L + j] = 3.0e38f;
   if (wave * 16 >= qlim) return;
   const int kt_end = CAUSAL ? wave + 1 : nt;
   f32x4 S[SNT];
@@ -625,7 +496,7 @@ __global__ __launch_bounds__(SNT * 64) void attn32s_fwd_kernel(Attn32Args a) {
       }
     }
   }
-  mx = quad_max32(mx);
+  mx = quad_max(mx);
   float sum = 0.f;
 #pragma unroll
   for (int kt = 0; kt < SNT; ++kt)
@@ -633,7 +504,7 @@ __global__ __launch_bounds__(SNT * 64) void attn32s_fwd_kernel(Attn32Args a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { S[kt][r] = __expf(S[kt][r] - mx); sum += S[kt][r]; }
     }
-  sum = quad_sum32(sum);
+  sum = quad_sum(sum);
   f32x4 O[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -658,17 +529,17 @@ __global__ __launch_bounds__(SNT * 64) void attn32s_bwd_kernel(Attn32BwdArgs a) 
   __shared__ float lse_s[SROWS], del_s[SROWS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
   const int n = blockIdx.y, h = blockIdx.x, L = a.L, d = a.H * 64;
-  const size_t ld = 3 * (size_t)d;
-  const float* base = a.qkv + (size_t)n * L * ld + h * 64;
-  const float* gbase = a.dout32 + (size_t)n * L * d + h * 64;
-  stage_rows(S0, base + d, ld, L, tid, SNT * 64);          // K
-  stage_rows(S1, base + 2 * d, ld, L, tid, SNT * 64);      // V
+  const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d, gld = 2 * (size_t)d;
+  const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
+  const T* gbase = (const T*)a.dout_split + (size_t)n * L * gld + h * 64;
+  stage_rows<T>(S0, base + d, lo, ld, L, tid, SNT * 64);          // K
+  stage_rows<T>(S1, base + 2 * d, lo, ld, L, tid, SNT * 64);      // V
   const size_t stat0 = ((size_t)n * a.H + h) * L;
   const int nt = (L + 15) >> 4;
   const int row = wave * 16 + fr, rc = row < L ? row : L - 1;     // own row: query in phase A, key in phase B
   f32x4 Q[4], dO[4];
-  load_own(Q, base + (size_t)rc * ld, fg);
-  load_own(dO, gbase + (size_t)rc * d, fg);
+  load_own<T>(Q, base + (size_t)rc * ld, lo, fg);
+  load_own<T>(dO, gbase + (size_t)rc * gld, d, fg);
   // delta = rowsum(dO * O) of the own query row (O as a hi|lo pair)
   float dl = 0.f;
   {
@@ -679,13 +550,13 @@ __global__ __launch_bounds__(SNT * 64) void attn32s_bwd_kernel(Attn32BwdArgs a) 
 #pragma unroll
       for (int e = 0; e < 4; ++e) dl += o[e] * dO[t][e];
     }
-    dl = quad_sum32(dl);
+    dl = quad_sum(dl);
   }
   const float lse = a.lse[stat0 + rc];
   if (fg == 0) { lse_s[row] = lse; del_s[row] = dl; }
   __syncthreads();
   const bool active = wave < nt;
-  T* orow = (T*)a.dqkv_split + ((size_t)n * L + rc) * (6 * (size_t)d) + h * 64;
+  T* orow = (T*)a.dqkv_split + ((size_t)n * L + rc) * ld + h * 64;
   f32x4 K[4], V[4];
   // ---- phase A: own query tile -> dQ
   if (active) {
@@ -709,14 +580,14 @@ __global__ __launch_bounds__(SNT * 64) void attn32s_bwd_kernel(Attn32BwdArgs a) 
       }
     if (row < L) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, 3 * (size_t)d, dQ[dt] * SCALE);
+      for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, lo, dQ[dt] * SCALE);
     }
-    load_own(K, S0 + row * RS, fg);                        // own key row for phase B, before the images are replaced
-    load_own(V, S1 + row * RS, fg);
+    load_own_lds(K, S0 + row * RS, fg);                    // own key row for phase B, before the images are replaced
+    load_own_lds(V, S1 + row * RS, fg);
   }
   __syncthreads();
-  stage_rows(S0, base, ld, L, tid, SNT * 64);              // Q
-  stage_rows(S1, gbase, d, L, tid, SNT * 64);              // dO
+  stage_rows<T>(S0, base, lo, ld, L, tid, SNT * 64);       // Q
+  stage_rows<T>(S1, gbase, d, gld, L, tid, SNT * 64);      // dO
   __syncthreads();
   // ---- phase B: own key tile -> dK, dV
   if (active) {
@@ -749,70 +620,73 @@ __global__ __launch_bounds__(SNT * 64) void attn32s_bwd_kernel(Attn32BwdArgs a) 
   }
 }
 
-// MVLPT_ATTN32_MODE: 0 = f32 MFMA (exact fp32 products), 1 (default) = three-term products on the 16-bit MFMA;
-// bit 1 (value 2 / 3) additionally routes short sequences (L <= 80) to the generic kernels (experiments)
-static int attn32_mode() {
-  static const int m = getenv("MVLPT_ATTN32_MODE") ? atoi(getenv("MVLPT_ATTN32_MODE")) : 1;
-  return m & 1;
+// workgroup height: 8 waves (256 own rows) stream the other side fewer times; 4 waves (128 rows) pad less.
+// MVLPT_ATTN32_NW = 4 / 8 forces one (experiments)
+static int attn32_nw(int rows) {
+  static const int forced = getenv("MVLPT_ATTN32_NW") ? atoi(getenv("MVLPT_ATTN32_NW")) : 0;
+  if (forced == 4 || forced == 8) return forced;
+  const int pad8 = (rows + 255) / 256 * 256, pad4 = (rows + 127) / 128 * 128;
+  return pad8 * 8 <= pad4 * 9 ? 8 : 4;          // take 256-row workgroups unless they add more than 1/8 of padding
 }
-static bool attn32_short_ok() {
-  static const int m = getenv("MVLPT_ATTN32_MODE") ? atoi(getenv("MVLPT_ATTN32_MODE")) : 1;
-  return (m & 2) == 0;
+template <typename K>
+static void set_lds(K kernel, int bytes) { (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
+
+template <typename T, bool CAUSAL, int NW>
+static hipError_t fwd_x(const Attn32Args& a, hipStream_t s) {
+  const int lq = a.q_rows > 0 ? (a.q_rows < a.L ? a.q_rows : a.L) : a.L;
+  const int nqc = (lq + NW * 32 - 1) / (NW * 32);
+  constexpr int lds = 8 * XIMG;
+  static bool set = false;
+  if (!set) { set_lds(attn32x_fwd_kernel<T, CAUSAL, NW>, lds); set = true; }
+  hipLaunchKernelGGL((attn32x_fwd_kernel<T, CAUSAL, NW>), dim3(stream_grid(a.N * a.H, nqc)), dim3(NW * 64), lds, s, a, nqc);
+  return hipGetLastError();
 }
+template <typename T, bool CAUSAL, int NW>
+static hipError_t bwd_x(const Attn32BwdArgs& a, hipStream_t s) {
+  const int nc = (a.L + NW * 32 - 1) / (NW * 32), lpad = (a.L + CH - 1) / CH * CH;
+  constexpr int lds = 8 * XIMG;
+  const int lds_kv = lds + 8 * lpad;
+  static int set = 0;
+  if (set < lds_kv) { set_lds(attn32x_dq_kernel<T, CAUSAL, NW>, lds); set_lds(attn32x_dkv_kernel<T, CAUSAL, NW>, lds_kv); set = lds_kv; }
+  const dim3 grid(stream_grid(a.N * a.H, nc)), block(NW * 64);
+  hipLaunchKernelGGL((attn32x_dq_kernel<T, CAUSAL, NW>), grid, block, lds, s, a, nc);
+  hipLaunchKernelGGL((attn32x_dkv_kernel<T, CAUSAL, NW>), grid, block, lds_kv, s, a, nc, lpad);
+  return hipGetLastError();
+}
+
 template <typename T>
 static hipError_t fwd_t(const Attn32Args& a, hipStream_t s) {
-  if (a.L <= SROWS && attn32_short_ok()) {
+  if (a.L <= SROWS) {
     dim3 grid(a.H, a.N), block(SNT * 64);
     if (a.causal) hipLaunchKernelGGL((attn32s_fwd_kernel<T, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((attn32s_fwd_kernel<T, false>), grid, block, 0, s, a);
     return hipGetLastError();
   }
   const int lq = a.q_rows > 0 ? (a.q_rows < a.L ? a.q_rows : a.L) : a.L;
-  dim3 grid((lq + CH - 1) / CH, a.H, a.N), block(256);
-  if (attn32_mode() == 0) {
-    if (a.causal) hipLaunchKernelGGL((attn32_fwd_kernel<T, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn32_fwd_kernel<T, false>), grid, block, 0, s, a);
-  } else {
-    if (a.causal) hipLaunchKernelGGL((attn32x_fwd_kernel<T, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn32x_fwd_kernel<T, false>), grid, block, 0, s, a);
-  }
-  return hipGetLastError();
+  if (attn32_nw(lq) == 8) return a.causal ? fwd_x<T, true, 8>(a, s) : fwd_x<T, false, 8>(a, s);
+  return a.causal ? fwd_x<T, true, 4>(a, s) : fwd_x<T, false, 4>(a, s);
 }
 template <typename T>
 static hipError_t bwd_t(const Attn32BwdArgs& a, hipStream_t s) {
-  if (a.L <= SROWS && attn32_short_ok()) {
+  if (a.L <= SROWS) {
     dim3 grid(a.H, a.N), block(SNT * 64);
     if (a.causal) hipLaunchKernelGGL((attn32s_bwd_kernel<T, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((attn32s_bwd_kernel<T, false>), grid, block, 0, s, a);
     return hipGetLastError();
   }
-  dim3 grid((a.L + CH - 1) / CH, a.H, a.N), block(256);
-  if (attn32_mode() == 0) {
-    if (a.causal) {
-      hipLaunchKernelGGL((attn32_dq_kernel<T, true>), grid, block, 0, s, a);
-      hipLaunchKernelGGL((attn32_dkv_kernel<T, true>), grid, block, 0, s, a);
-    } else {
-      hipLaunchKernelGGL((attn32_dq_kernel<T, false>), grid, block, 0, s, a);
-      hipLaunchKernelGGL((attn32_dkv_kernel<T, false>), grid, block, 0, s, a);
-    }
-  } else if (a.causal) {
-    hipLaunchKernelGGL((attn32x_dq_kernel<T, true>), grid, block, 0, s, a);
-    hipLaunchKernelGGL((attn32x_dkv_kernel<T, true>), grid, block, 0, s, a);
-  } else {
-    hipLaunchKernelGGL((attn32x_dq_kernel<T, false>), grid, block, 0, s, a);
-    hipLaunchKernelGGL((attn32x_dkv_kernel<T, false>), grid, block, 0, s, a);
-  }
-  return hipGetLastError();
+  if (a.L > 8192) return hipErrorInvalidValue;       // the dK/dV kernel keeps lse and delta of a whole sequence in LDS
+  if (attn32_nw(a.L) == 8) return a.causal ? bwd_x<T, true, 8>(a, s) : bwd_x<T, false, 8>(a, s);
+  return a.causal ? bwd_x<T, true, 4>(a, s) : bwd_x<T, false, 4>(a, s);
 }
 
 hipError_t launch_attn32_fwd(int dtype, const Attn32Args& a, hipStream_t s) {
-  if (a.L <= 0 || a.N <= 0 || a.H <= 0 || !a.qkv || !a.out_split) return hipErrorInvalidValue;
+  if (a.L <= 0 || a.N <= 0 || a.H <= 0 || !a.qkv_split || !a.out_split) return hipErrorInvalidValue;
   if (dtype == DT_F16) return fwd_t<f16>(a, s);
   if (dtype == DT_BF16) return fwd_t<bf16>(a, s);
   return hipErrorInvalidValue;
 }
 hipError_t launch_attn32_bwd(int dtype, const Attn32BwdArgs& a, hipStream_t s) {
-  if (a.L <= 0 || a.N <= 0 || a.H <= 0 || !a.qkv || !a.out_split || !a.dout32 || !a.lse || !a.delta || !a.dqkv_split)
+  if (a.L <= 0 || a.N <= 0 || a.H <= 0 || !a.qkv_split || !a.out_split || !a.dout_split || !a.lse || !a.delta || !a.dqkv_split)
     return hipErrorInvalidValue;
   if (dtype == DT_F16) return bwd_t<f16>(a, s);
   if (dtype == DT_BF16) return bwd_t<bf16>(a, s);

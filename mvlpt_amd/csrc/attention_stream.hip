@@ -24,19 +24,6 @@ __device__ __forceinline__ bool map_block(int nheads, int nchunks, int& nh, int&
 }
 static int stream_grid(int nheads, int nchunks) { return ((nheads + 7) / 8) * 8 * nchunks; }
 
-// LDS-DMA issued from inline assembly.  With the builtin, the compiler's wait-count pass knows an LDS write is in
-// flight and puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 — which would serialise the DMA of chunk
-// c+1 behind the arithmetic on chunk c.  Through asm the only waits are the counted ones written in the kernels
-// (the memory clobber keeps the compiler from moving LDS reads across them).  M0 carries the wave-uniform LDS base.
-template <int BYTES>
-__device__ __forceinline__ void dma_raw(const void* gsrc, const void* lds_wave_base) {
-  const unsigned m0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_wave_base);
-  if constexpr (BYTES == 16)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m0) : "memory", "m0");
-  else
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(m0) : "memory", "m0");
-}
-
 // DMA one 64-row chunk (rows row0 .. row0+63 of `src`, row stride ld) into `dst`; 2 slabs per wave
 template <typename T>
 __device__ __forceinline__ void stage_chunk(char* dst, const T* src, size_t ld, int row0, int L, int wave, int lane) {

@@ -149,7 +149,7 @@ hipError_t gemm(Engine* E, int epi, const void* A, const void* Bt, int M, int N,
   GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
   g.a_split = a_split;
   const int dt = dtype >= 0 ? dtype : E->dt;
-  const double ob = (epi == EPI_RESID32) ? 8.0 : (epi == EPI_STORE32 ? 4.0 : ((epi == EPI_GELUBWD || epi == EPI_GELU_SPLIT) ? 4.0 :
+  const double ob = (epi == EPI_RESID32) ? 8.0 : ((epi == EPI_STORE32 || epi == EPI_STORE_SPLIT) ? 4.0 : ((epi == EPI_GELUBWD || epi == EPI_GELU_SPLIT) ? 4.0 :
                     (epi == EPI_GELUBWD_SPLIT ? 6.0 : 2.0)));
   // the dominant kernel is timed by its own dispatch (start/stop timestamps of the AQL packet): no marker packets
   hipEvent_t ea = nullptr, eb = nullptr;
@@ -227,14 +227,14 @@ void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool s
 
 // fp32 attention core of the split-precision mode: qkv32 [T,3d] -> O as a hi|lo pair [T,2d]
 int attn32_fwd(Engine* E, TowerState& st, int l, int q_rows, hipStream_t s) {
-  Attn32Args a{(const float*)st.qkv[l], st.attn[l], st.saved ? st.lse[l] : nullptr, st.N, st.L, st.H, st.causal ? 1 : 0, q_rows};
+  Attn32Args a{st.qkv[l], st.attn[l], st.saved ? st.lse[l] : nullptr, st.N, st.L, st.H, st.causal ? 1 : 0, q_rows};
   const double rows = q_rows > 0 ? (double)q_rows : (double)st.L;
   ProfScope ps(E, s, PC_ATTN_FWD, 4.0 * rows * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0), (double)st.N * st.L * st.d * 16.0);
   HIPCHK(E, launch_attn32_fwd(E->dt, a, s));
   return 0;
 }
 int attn32_bwd(Engine* E, TowerState& st, int l, hipStream_t s) {
-  Attn32BwdArgs a{(const float*)st.qkv[l], st.attn[l], (const float*)st.dO16, st.lse[l], st.delta, st.dqkv16, st.N, st.L, st.H, st.causal ? 1 : 0};
+  Attn32BwdArgs a{st.qkv[l], st.attn[l], st.dO16, st.lse[l], st.delta, st.dqkv16, st.N, st.L, st.H, st.causal ? 1 : 0};
   ProfScope ps(E, s, PC_ATTN_BWD, 14.0 * st.L * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0), (double)st.N * st.L * st.d * 32.0);
   HIPCHK(E, launch_attn32_bwd(E->dt, a, s));
   return 0;
@@ -247,7 +247,7 @@ int block_fwd_x(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s
   const int T = st.N * st.L, d = st.d;
   float* xin = st.x[2 * l]; float* xmid = st.x[2 * l + 1]; float* xout = st.x[2 * l + 2];
   HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, B.ln1, st.h16, T, d, s, 1));
-  HIPCHK(E, gemm(E, EPI_STORE32, st.h16, B.qkv.w, T, 3 * d, d, B.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, 1));
+  HIPCHK(E, gemm(E, EPI_STORE_SPLIT, st.h16, B.qkv.w, T, 3 * d, d, B.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, 1));
   if (int rc = attn32_fwd(E, st, l, 0, s)) return rc;
   HIPCHK(E, gemm(E, EPI_RESID32, st.attn[l], B.o.w, T, d, d, B.o.b, nullptr, xin, xmid, nullptr, s, -1, 1));
   HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, B.ln2, st.h16, T, d, s, 1));
@@ -261,7 +261,7 @@ int block_bwd_x(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s
   HIPCHK(E, gemm(E, EPI_GELUBWD_SPLIT, st.dx16, B.pr.wt, T, 4 * d, d, nullptr, st.u[l], nullptr, st.du16, nullptr, s, -1, 1));
   HIPCHK(E, gemm(E, EPI_STORE32, st.du16, B.fc.wt, T, d, 4 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, 1));
   HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l + 1], nullptr, 1, B.ln2, st.dx32, st.dx32, st.dx16, T, d, s, -1, 1));
-  HIPCHK(E, gemm(E, EPI_STORE32, st.dx16, B.o.wt, T, d, d, nullptr, nullptr, nullptr, st.dO16, nullptr, s, -1, 1));
+  HIPCHK(E, gemm(E, EPI_STORE_SPLIT, st.dx16, B.o.wt, T, d, d, nullptr, nullptr, nullptr, st.dO16, nullptr, s, -1, 1));
   if (int rc = attn32_bwd(E, st, l, s)) return rc;
   HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, B.qkv.wt, T, d, 3 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, 1));
   HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, B.ln1, st.dx32, st.dx32, st.dx16, T, d, s, -1, 1));
@@ -593,7 +593,7 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
     E->v_cls_last = save;
     const int xs = st.exact ? 1 : 0;      // split-precision operands (hi|lo pairs, twice the columns) + fp32 attention
     HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dv, s, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_STORE32 : EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dv, dv, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dv, dv, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
     if (xs) {
       // only the CLS rows of the attention output are produced: the backward (delta = rowsum(dO * O) over EVERY row, with
       // dO = 0 off the CLS rows) must not meet uninitialised memory there
@@ -647,7 +647,7 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
     HIPCHK(E, gemm(E, xs ? EPI_GELUBWD_SPLIT : EPI_GELUBWD, E->dxc16, Bk.pr.wt, B, 4 * dv, dv, nullptr, E->uc16, nullptr, E->duc16, nullptr, s, -1, xs));
     HIPCHK(E, gemm(E, EPI_STORE32, E->duc16, Bk.fc.wt, B, dv, 4 * dv, nullptr, nullptr, nullptr, E->dhc32, nullptr, s, -1, xs));
     HIPCHK(E, ln_bwd(E, E->dhc32, DT_F32, E->xcm32, nullptr, 1, Bk.ln2, E->dxc32, E->dxc32, E->dxc16, B, dv, s, -1, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_STORE32 : EPI_STORE16, E->dxc16, Bk.o.wt, B, dv, dv, nullptr, nullptr, nullptr, E->dOc16, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, E->dxc16, Bk.o.wt, B, dv, dv, nullptr, nullptr, nullptr, E->dOc16, nullptr, s, -1, xs));
     if (xs) {
       // fp32 attention backward at full width on a dO that is zero except for the CLS rows
       { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 4.0);
@@ -743,7 +743,7 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
     E->t_eot_last = save;
     const int xs = st.exact ? 1 : 0;
     HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dtw, s, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_STORE32 : EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dtw, dtw, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dtw, dtw, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
     if (xs) {
       if (int rc = attn32_fwd(E, st, l, 0, s)) return rc;
     } else {
@@ -793,9 +793,9 @@ int mvlpt_text_bwd(void* h, const float* dfeat, float* dctx, mvlpt_stream_t stre
     HIPCHK(E, gemm(E, xs ? EPI_GELUBWD_SPLIT : EPI_GELUBWD, E->tdxc16, Bk.pr.wt, C, 4 * dtw, dtw, nullptr, E->tuc16, nullptr, E->tduc16, nullptr, s, -1, xs));
     HIPCHK(E, gemm(E, EPI_STORE32, E->tduc16, Bk.fc.wt, C, dtw, 4 * dtw, nullptr, nullptr, nullptr, E->tdhc32, nullptr, s, -1, xs));
     HIPCHK(E, ln_bwd(E, E->tdhc32, DT_F32, E->txm32, nullptr, 1, Bk.ln2, E->tdxc32, E->tdxc32, E->tdxc16, C, dtw, s, -1, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_STORE32 : EPI_STORE16, E->tdxc16, Bk.o.wt, C, dtw, dtw, nullptr, nullptr, nullptr, E->tdOc16, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, E->tdxc16, Bk.o.wt, C, dtw, dtw, nullptr, nullptr, nullptr, E->tdOc16, nullptr, s, -1, xs));
     { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dtw * 2.0);
-      HIPCHK(E, launch_zero(st.dO16, T * dtw * 2 * X, s));      // (exact: dO is fp32)
+      HIPCHK(E, launch_zero(st.dO16, T * dtw * 2 * X, s));      // (exact: dO is a hi|lo pair)
       HIPCHK(E, launch_copy_rows(E->tdOc16, st.dO16, E->eot_rows, C, (int)(dtw * 2 * X), 1, s));
       HIPCHK(E, launch_copy_rows(E->tdxc32, st.dx32, E->eot_rows, C, dtw * 4, 1, s)); }     // residual path (dx32 was zeroed)
     if (xs) {
@@ -914,13 +914,13 @@ int mvlpt_op_layernorm_bwd_split(int dtype, const void* dy, const float* x, cons
   OPCHK(launch_ln_bwd(dtype, a, (hipStream_t)stream));
   return 0;
 }
-int mvlpt_op_attention32_fwd(int dtype, const float* qkv, void* out, float* lse, int N, int L, int H, int causal, int q_rows,
+int mvlpt_op_attention32_fwd(int dtype, const void* qkv, void* out, float* lse, int N, int L, int H, int causal, int q_rows,
                              mvlpt_stream_t stream) {
   Attn32Args a{qkv, out, lse, N, L, H, causal, q_rows};
   OPCHK(launch_attn32_fwd(dtype, a, (hipStream_t)stream));
   return 0;
 }
-int mvlpt_op_attention32_bwd(int dtype, const float* qkv, const void* out, const float* dout, const float* lse, float* delta,
+int mvlpt_op_attention32_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                              void* dqkv, int N, int L, int H, int causal, mvlpt_stream_t stream) {
   Attn32BwdArgs a{qkv, out, dout, lse, delta, dqkv, N, L, H, causal};
   OPCHK(launch_attn32_bwd(dtype, a, (hipStream_t)stream));

@@ -149,13 +149,14 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
 #pragma unroll
           for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(v[e] * quick_gelu_grad(to_f32<T>(uv[i][it][e])));
           if (m < M) __builtin_nontemporal_store(w, (v4*)((T*)g.out + o));
-        } else if constexpr (EPI == EPI_GELU_SPLIT || EPI == EPI_GELUBWD_SPLIT) {
+        } else if constexpr (EPI == EPI_GELU_SPLIT || EPI == EPI_GELUBWD_SPLIT || EPI == EPI_STORE_SPLIT) {
           v4 hi, lo, u16;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float r;
             if constexpr (EPI == EPI_GELU_SPLIT) { r = quick_gelu(v[e]); u16[e] = from_f32<T>(v[e]); }
-            else r = v[e] * quick_gelu_grad(to_f32<T>(uv[i][it][e]));
+            else if constexpr (EPI == EPI_GELUBWD_SPLIT) r = v[e] * quick_gelu_grad(to_f32<T>(uv[i][it][e]));
+            else r = v[e];
             T h, l;
             split16<T>(r, h, l);
             hi[e] = h; lo[e] = l;
@@ -590,7 +591,7 @@ template <int EPI>
 static GemmArgs row_slice(const GemmArgs& g, int m_lo, int rows) {
   GemmArgs r = g;
   const size_t ok = (size_t)m_lo * g.K * (g.a_split ? 2 : 1), on = (size_t)m_lo * g.N;
-  constexpr size_t OB = (EPI == EPI_RESID32 || EPI == EPI_STORE32 || EPI == EPI_GELU_SPLIT || EPI == EPI_GELUBWD_SPLIT) ? 4 : 2;
+  constexpr size_t OB = (EPI == EPI_RESID32 || EPI == EPI_STORE32 || EPI == EPI_GELU_SPLIT || EPI == EPI_GELUBWD_SPLIT || EPI == EPI_STORE_SPLIT) ? 4 : 2;
   r.A = (const char*)g.A + ok * 2;
   r.M = rows;
   r.out = (char*)g.out + on * OB;
@@ -679,6 +680,7 @@ static hipError_t launch_epi(const GemmArgs& g, int epi, hipStream_t s, hipEvent
     case EPI_STORE32: return launch_t<T, EPI_STORE32>(g, s, ea, eb);
     case EPI_GELU_SPLIT: return launch_t<T, EPI_GELU_SPLIT>(g, s, ea, eb);
     case EPI_GELUBWD_SPLIT: return launch_t<T, EPI_GELUBWD_SPLIT>(g, s, ea, eb);
+    case EPI_STORE_SPLIT: return launch_t<T, EPI_STORE_SPLIT>(g, s, ea, eb);
   }
   return hipErrorInvalidValue;
 }

@@ -16,6 +16,7 @@ enum GemmEpi {
   // [hi(0..N) | lo(0..N)], i.e. directly the `a_split` A operand of the next GEMM
   EPI_GELU_SPLIT = 5,     // u = acc+bias ; out2 (optional, 16-bit [M,N]) = u ; out [M,2N] = split(QuickGELU(u))
   EPI_GELUBWD_SPLIT = 6,  // out [M,2N] = split(acc * QuickGELU'(aux16))
+  EPI_STORE_SPLIT = 7,    // out [M,2N] = split(acc (+bias))
 };
 struct GemmArgs {
   const void* A;       // [M,K] 16-bit
@@ -92,10 +93,11 @@ hipError_t launch_attn_fwd_stream(int dtype, const AttnArgs& a, hipStream_t s);
 hipError_t launch_attn_bwd_stream(int dtype, const AttnBwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- fp32 attention (attention32.hip), any L
-// Split-precision mode of the towers that carry a gradient: fp32 Q/K/V in, fp32 arithmetic on the f32 MFMA, outputs as
-// 16-bit hi|lo pairs that are directly the `a_split` A operand of the next GEMM.
+// Split-precision mode of the towers that carry a gradient: every operand is a 16-bit hi|lo pair [rows, 2*cols]
+// (hi = round16(x), lo = round16(x - hi)), products keep hi*hi + hi*lo + lo*hi on the 16-bit MFMA (fp32 accumulation);
+// the outputs are pairs again: directly the `a_split` A operand of the next GEMM.
 struct Attn32Args {
-  const float* qkv;      // [N*L, 3d] fp32, columns [q | k | v], head h at h*64 inside each third
+  const void* qkv_split; // [N*L, 6d] 16-bit: [hi(q|k|v) | lo(q|k|v)], head h at h*64 inside each d-wide block
   void* out_split;       // [N*L, 2d] 16-bit: [hi(d) | lo(d)]
   float* lse;            // [N*H*L] or null
   int N, L, H; int causal;
@@ -103,7 +105,7 @@ struct Attn32Args {
 };
 hipError_t launch_attn32_fwd(int dtype, const Attn32Args& a, hipStream_t s);
 struct Attn32BwdArgs {
-  const float* qkv; const void* out_split; const float* dout32 /*[N*L,d] fp32*/; const float* lse;
+  const void* qkv_split; const void* out_split; const void* dout_split /*[N*L, 2d]*/; const float* lse;
   float* delta /*[N*H*L] scratch*/; void* dqkv_split /*[N*L, 6d] 16-bit: [hi(3d) | lo(3d)]*/;
   int N, L, H; int causal;
 };

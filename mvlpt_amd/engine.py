@@ -294,7 +294,7 @@ def op_gemm_split(A2, Bt, epi=_lib.EPI_STORE32, bias=None, aux=None, resid=None,
     N = Bt.shape[0]
     if epi in (_lib.EPI_RESID32, _lib.EPI_STORE32):
         out = torch.empty(M, N, device=A2.device, dtype=torch.float32)
-    elif epi in (_lib.EPI_GELU_SPLIT, _lib.EPI_GELUBWD_SPLIT):
+    elif epi in (_lib.EPI_GELU_SPLIT, _lib.EPI_GELUBWD_SPLIT, _lib.EPI_STORE_SPLIT):
         out = torch.empty(M, 2 * N, device=A2.device, dtype=A2.dtype)
     else:
         out = torch.empty(M, N, device=A2.device, dtype=A2.dtype)
@@ -321,20 +321,33 @@ def op_layernorm_bwd_split(dy32, x, gamma, dtype, resid=None):
     return out32, out16
 
 
-def op_attention32_fwd(qkv32, N, L, H, causal, dtype=torch.float16, q_rows=0):
-    out = torch.zeros(N * L, 2 * H * 64, device=qkv32.device, dtype=dtype)
-    lse = torch.zeros(N * H * L, device=qkv32.device, dtype=torch.float32)
-    _lib.check(lib.mvlpt_op_attention32_fwd(_TORCH2DT[dtype], _ptr(qkv32), _ptr(out), _ptr(lse), N, L, H, int(causal), q_rows,
+def op_attention32_fwd_pair(qkv_pair, N, L, H, causal, q_rows=0):
+    """Split-precision attention core: qkv hi|lo pair [N*L, 6d] -> (O pair [N*L, 2d], lse)."""
+    dtype = qkv_pair.dtype
+    out = torch.zeros(N * L, 2 * H * 64, device=qkv_pair.device, dtype=dtype)
+    lse = torch.zeros(N * H * L, device=qkv_pair.device, dtype=torch.float32)
+    _lib.check(lib.mvlpt_op_attention32_fwd(_TORCH2DT[dtype], _ptr(qkv_pair), _ptr(out), _ptr(lse), N, L, H, int(causal), q_rows,
                                             _stream()), None, "op_attention32_fwd")
     return out, lse
 
 
-def op_attention32_bwd(qkv32, out_pair, dout32, lse, N, L, H, causal):
-    dqkv = torch.empty(N * L, 6 * H * 64, device=qkv32.device, dtype=out_pair.dtype)
-    delta = torch.empty(N * H * L, device=qkv32.device, dtype=torch.float32)
-    _lib.check(lib.mvlpt_op_attention32_bwd(_TORCH2DT[out_pair.dtype], _ptr(qkv32), _ptr(out_pair), _ptr(dout32), _ptr(lse),
+def op_attention32_bwd_pair(qkv_pair, out_pair, dout_pair, lse, N, L, H, causal):
+    dtype = out_pair.dtype
+    dqkv = torch.empty(N * L, 6 * H * 64, device=qkv_pair.device, dtype=dtype)
+    delta = torch.empty(N * H * L, device=qkv_pair.device, dtype=torch.float32)
+    _lib.check(lib.mvlpt_op_attention32_bwd(_TORCH2DT[dtype], _ptr(qkv_pair), _ptr(out_pair), _ptr(dout_pair), _ptr(lse),
                                             _ptr(delta), _ptr(dqkv), N, L, H, int(causal), _stream()), None, "op_attention32_bwd")
     return dqkv
+
+
+def op_attention32_fwd(qkv32, N, L, H, causal, dtype=torch.float16, q_rows=0):
+    """Same on fp32 inputs, split to pairs here (as the QKV GEMM's epilogue does in the engine)."""
+    return op_attention32_fwd_pair(split_pair(qkv32, dtype), N, L, H, causal, q_rows)
+
+
+def op_attention32_bwd(qkv32, out_pair, dout32, lse, N, L, H, causal):
+    dtype = out_pair.dtype
+    return op_attention32_bwd_pair(split_pair(qkv32, dtype), out_pair, split_pair(dout32, dtype), lse, N, L, H, causal)
 
 
 def op_layernorm_fwd(x, gamma, beta, out_dtype):

@@ -207,6 +207,8 @@ def test_gemm_split_epilogues(dtype):
     # the device's QuickGELU uses v_exp/v_rcp (~1 ulp each): fp32-level agreement, not pair-level
     assert relerr(E.join_pair(a_pair), O.quick_gelu(acc + bias)) < 2e-6 * (1 if dtype == torch.float16 else 40)
     assert relerr(u16, acc + bias) < TOL[dtype]
+    s_pair = E.op_gemm_split(A2, Bt.cuda(), E._lib.EPI_STORE_SPLIT, bias=bias.cuda())
+    assert s_pair.shape == (M, 2 * N) and relerr(E.join_pair(s_pair), acc + bias) < SPLIT_TOL[dtype]
     u = torch.randn(M, N, generator=g).to(dtype)
     d_pair = E.op_gemm_split(A2, Bt.cuda(), E._lib.EPI_GELUBWD_SPLIT, aux=u.cuda())
     assert relerr(E.join_pair(d_pair), acc * O.quick_gelu_grad(u.float())) < 2e-6 * (1 if dtype == torch.float16 else 40)
@@ -261,6 +263,21 @@ def test_attention32_fwd_bwd(L, causal):
         o1, _ = E.op_attention32_fwd(qkv.cuda(), N, L, H, causal, q_rows=1)
         got = E.join_pair(o1).cpu().reshape(N, L, d)
         assert relerr(got[:, 0], o_ref.reshape(N, L, d)[:, 0]) < 5e-6 and float(got[:, 1:].abs().max()) == 0.0
+        # ... and the backward over the whole sequence (dO = 0 off the CLS rows) must see P = 0 on the rows that were never
+        # computed, whatever their lse buffer held before: the op marks them with lse = +huge
+        lse1 = torch.full((N * H * L,), float("nan"), device="cuda")
+        qp = E.split_pair(qkv.cuda(), torch.float16)
+        o1 = torch.zeros(N * L, 2 * d, device="cuda", dtype=torch.float16)
+        E._lib.check(E.lib.mvlpt_op_attention32_fwd(1, qp.data_ptr(), o1.data_ptr(), lse1.data_ptr(), N, L, H, 0, 1,
+                                                    torch.cuda.current_stream().cuda_stream), None, "fwd")
+        l1 = lse1.cpu().reshape(N, H, L)
+        assert bool(torch.isfinite(l1).all()) and float(l1[:, :, 1:].min()) > 1e37
+        d_cls = torch.zeros(N, L, d)
+        d_cls[:, 0] = dout.reshape(N, L, d)[:, 0]
+        dq, dk, dv = O.attention_bwd(d_cls.reshape(N, L, H, 64).permute(0, 2, 1, 3), q, k, v, p)
+        ref1 = torch.cat([t.permute(0, 2, 1, 3).reshape(N * L, d) for t in (dq, dk, dv)], dim=-1)
+        got1 = E.join_pair(E.op_attention32_bwd_pair(qp, o1, E.split_pair(d_cls.reshape(N * L, d).cuda(), torch.float16), lse1, N, L, H, False))
+        assert bool(torch.isfinite(got1).all()) and relerr(got1, ref1) < 1e-5
 
 
 def test_attention32_is_not_transposed():
