@@ -11,7 +11,7 @@
 //
 // Arithmetic: a product of two pairs keeps the three terms  hi*hi + hi*lo + lo*hi  on the 16-bit MFMA with fp32
 // accumulation (the dropped lo*lo is 2^-22 of the product); softmax, P, dS are fp32 registers that are split in place
-// right where the fast-mode kernels round them.  The short-sequence kernels (text tower) still multiply on the f32 MFMA.
+// right where the fast-mode kernels round them.
 //
 // Structure of the streamed kernels (fwd, dQ, dK/dV): a workgroup of 4 waves owns 64 rows (queries, or keys in the
 // dK/dV kernel), 16 per wave, whose operands stay in registers; the other side is streamed in 64-row chunks: four
@@ -27,12 +27,9 @@
 namespace mvlpt {
 
 namespace {
-constexpr int RS = 68;                 // padded fp32 LDS row (floats) of the short kernels
 constexpr int CH = 64;                 // streamed chunk / rows per workgroup
 constexpr int XIMG = CH * 128;         // one 64 x 64 16-bit image
 constexpr float SCALE = 0.125f;        // 1/sqrt(64)
-
-__device__ __forceinline__ f32x4 mfma32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // 16-bit pair store of 4 consecutive values: hi at p, lo at p + lo_off
 template <typename T>
@@ -414,207 +411,242 @@ __global__ __launch_bounds__(NW * 64) void attn32x_dkv_kernel(Attn32BwdArgs a, i
 
 // ------------------------------------------------------------------------------------------------ short sequences
 // L <= 80 (every text sequence: context_length 77; the tiny test towers): ONE workgroup of 5 waves per (sequence, head),
-// wave t owns the 16-row tile t; all of K, V (forward) or Q, K, V, dO (backward) are staged in LDS once, so the whole
-// head costs two barriers instead of a staged chunk per 64 rows per pass, and the backward runs dQ and dK/dV in one
-// launch (100 classes x 8 heads x 12 layers of L = 77: 151 -> ~30 us per layer for the backward).
+// wave t owns the 16-row tile t; all of K, V (forward) or K, V then Q, dO (backward) are staged in LDS once by LDS-DMA, so
+// the whole head costs two barriers instead of a staged chunk per 64 rows per pass, and the backward runs dQ and dK/dV in
+// one launch.  100 classes x 8 heads, L = 77: forward 15 us, backward 49 us (the same structure on the f32-input MFMA,
+// v_mfma_f32_16x16x4_f32 at 1/16 of the 16-bit rate, took 24 / 72 us; it lives in the history before this commit).
 namespace {
 constexpr int SNT = 5, SROWS = SNT * 16;           // tiles / padded rows
+constexpr int TIMG = SROWS * 128;                  // one 80 x 64 16-bit image
 
-// pair rows -> fp32 LDS rows (hi + lo is exact in fp32)
+// all SROWS rows of a pair matrix -> hi and lo images (10 slabs of 8 rows each, two per wave)
 template <typename T>
-__device__ __forceinline__ void stage_rows(float* dst, const T* src, size_t lo_off, size_t ld, int L, int tid, int nthreads) {
-  for (int idx = tid; idx < SROWS * 16; idx += nthreads) {
-    const int r = idx >> 4, c = (idx & 15) * 4;
-    const int row = r < L ? r : L - 1;
-    *(f32x4*)(dst + r * RS + c) = load_pair4<T>(src + (size_t)row * ld + c, lo_off);
+__device__ __forceinline__ void stage_short(char* hi, char* lo, const T* src, size_t lo_off, size_t ld, int L, int wave, int lane) {
+  const int srow = lane >> 3, chunk = (lane & 7) ^ srow;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int sl = wave + SNT * i;
+    int row = sl * 8 + srow;
+    row = row < L ? row : L - 1;
+    const T* g = src + (size_t)row * ld + chunk * 8;
+    dma_raw<16>(g, hi + sl * 1024);
+    dma_raw<16>(g + lo_off, lo + sl * 1024);
   }
 }
-// own-row operand fragment: X[row][16t + 4fg + s], t = 0..3 (register-resident for the whole kernel)
+// one streamed 16-row tile against the own rows: lane holds [own = fr][streamed = 16*kt + 4fg + r]
 template <typename T>
-__device__ __forceinline__ void load_own(f32x4 (&reg)[4], const T* row_ptr, size_t lo_off, int fg) {
+__device__ __forceinline__ f32x4 tile_rows3(const char* hi, const char* lo, int kt, const typename Vec<T>::v8 (&oh)[2],
+                                            const typename Vec<T>::v8 (&ol)[2], int fr, int fg) {
+  f32x4 acc[2];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) reg[t] = load_pair4<T>(row_ptr + 16 * t + 4 * fg, lo_off);
+  for (int ks = 0; ks < 2; ++ks) {
+    const typename Vec<T>::v8 ah = frag_rows<T>(hi, kt, ks, fr, fg), al = frag_rows<T>(lo, kt, ks, fr, fg);
+    acc[ks] = mfma16<T>(ah, oh[ks], f32x4{0.f, 0.f, 0.f, 0.f});
+    acc[ks] = mfma16<T>(ah, ol[ks], acc[ks]);
+    acc[ks] = mfma16<T>(al, oh[ks], acc[ks]);
+  }
+  return acc[0] + acc[1];
 }
-__device__ __forceinline__ void load_own_lds(f32x4 (&reg)[4], const float* row_ptr, int fg) {
+// out[dt] += sum over the 32 streamed rows of block kb of p * C; p0 / p1 are the block's two 16-row tiles (p1 must be 0
+// where the tile does not exist); HALF: the block has only its first tile (kb = 2 of a 5-tile sequence)
+template <typename T, bool HALF>
+__device__ __forceinline__ void block_accum3(f32x4 (&out)[4], const char* hi, const char* lo, int kb, const f32x4& p0, const f32x4& p1,
+                                             int fr, int fg) {
+  using v8 = typename Vec<T>::v8;
+  v8 ph, pl;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) reg[t] = *(const f32x4*)(row_ptr + 16 * t + 4 * fg);
+  for (int e = 0; e < 4; ++e) {
+    T x, y;
+    split16<T>(p0[e], x, y); ph[e] = x; pl[e] = y;
+    split16<T>(p1[e], x, y); ph[e + 4] = x; pl[e + 4] = y;
+  }
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const v8 vh = HALF ? frag_vt_half<T>(hi, kb, dt, fr, fg) : frag_vt<T>(hi, kb, dt, fr, fg);
+    const v8 vl = HALF ? frag_vt_half<T>(lo, kb, dt, fr, fg) : frag_vt<T>(lo, kb, dt, fr, fg);
+    out[dt] = mfma16<T>(vh, ph, out[dt]);
+    out[dt] = mfma16<T>(vh, pl, out[dt]);
+    out[dt] = mfma16<T>(vl, ph, out[dt]);
+  }
 }
-// one 16-row tile of the streamed side: lane holds [own = fr][streamed = 16*kt + 4fg + r]
-__device__ __forceinline__ f32x4 mm_tile(const float* lds, int kt, const f32x4 (&own)[4], int fr, int fg) {
-  f32x4 a[4];                                     // four independent chains (one per 16-wide slice of the head dimension)
-#pragma unroll
-  for (int t = 0; t < 4; ++t) a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 c[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) c[t] = *(const f32x4*)(lds + (16 * kt + fr) * RS + 16 * t + 4 * fg);
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a[t] = mfma32(c[t][s], own[t][s], a[t]);
-  return (a[0] + a[1]) + (a[2] + a[3]);
-}
-__device__ __forceinline__ void accum_tile(f32x4 (&out)[4], const float* lds, int kt, const f32x4& p, int fr, int fg) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) out[dt] = mfma32(lds[(16 * kt + 4 * fg + r) * RS + 16 * dt + fr], p[r], out[dt]);
+// p[0..4] (tile kt zero where unused) times the image: blocks 0, 1 full, block 2 = tile 4 alone
+template <typename T>
+__device__ __forceinline__ void accum_all3(f32x4 (&out)[4], const char* hi, const char* lo, const f32x4 (&p)[SNT], int t_lo, int t_hi,
+                                           int fr, int fg) {
+  // tiles t_lo .. t_hi-1 are non-zero (wave-uniform bounds)
+  if (t_lo < 2 && t_hi > 0) block_accum3<T, false>(out, hi, lo, 0, p[0], p[1], fr, fg);
+  if (t_lo < 4 && t_hi > 2) block_accum3<T, false>(out, hi, lo, 1, p[2], p[3], fr, fg);
+  if (t_hi > 4) block_accum3<T, true>(out, hi, lo, 2, p[4], f32x4{0.f, 0.f, 0.f, 0.f}, fr, fg);
 }
 }  // namespace
 
 template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(SNT * 64) void attn32s_fwd_kernel(Attn32Args a) {
-  __shared__ __attribute__((aligned(16))) float Ks[SROWS * RS];
-  __shared__ __attribute__((aligned(16))) float Vs[SROWS * RS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+__global__ __launch_bounds__(SNT * 64) void attn32t_fwd_kernel(Attn32Args a) {
+  __shared__ __attribute__((aligned(16))) char sm[4 * TIMG];
+  char *Kh = sm, *Kl = sm + TIMG, *Vh = sm + 2 * TIMG, *Vl = sm + 3 * TIMG;
+  using v8 = typename Vec<T>::v8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
   const int n = blockIdx.y, h = blockIdx.x, L = a.L, d = a.H * 64;
   const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d;
   const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
-  stage_rows<T>(Ks, base + d, lo, ld, L, tid, SNT * 64);
-  stage_rows<T>(Vs, base + 2 * d, lo, ld, L, tid, SNT * 64);
+  stage_short<T>(Kh, Kl, base + d, lo, ld, L, wave, lane);
+  stage_short<T>(Vh, Vl, base + 2 * d, lo, ld, L, wave, lane);
   const int nt = (L + 15) >> 4;
   const int qlim = a.q_rows > 0 ? (a.q_rows < L ? a.q_rows : L) : L;
   const int q = wave * 16 + fr, qc = q < L ? q : L - 1;
-  f32x4 Q[4];
-  load_own<T>(Q, base + (size_t)qc * ld, lo, fg);
+  v8 Qh[2], Ql[2];
+  load_own_pair<T>(Qh, Ql, base + (size_t)qc * ld, lo, fg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (a.lse && qlim < L)          // rows that are not computed: lse = +huge (P = 0 in a backward over the full sequence)
     for (int j = qlim + tid; j < L; j += SNT * 64) a.lse[((size_t)n * a.H + h) * L + j] = 3.0e38f;
-  if (wave * 16 >= qlim) return;
+  if (wave * 16 >= qlim || wave >= nt) return;
   const int kt_end = CAUSAL ? wave + 1 : nt;
   f32x4 S[SNT];
   float mx = -INFINITY;
 #pragma unroll
   for (int kt = 0; kt < SNT; ++kt) {
+    S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (kt < kt_end) {
-      S[kt] = mm_tile(Ks, kt, Q, fr, fg);
+      S[kt] = tile_rows3<T>(Kh, Kl, kt, Qh, Ql, fr, fg);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kk = 16 * kt + 4 * fg + r;
         const bool ok = kk < L && (!CAUSAL || kk <= q);
-        S[kt][r] = ok ? S[kt][r] * SCALE : -INFINITY;
+        S[kt][r] = ok ? S[kt][r] : -INFINITY;
         mx = fmaxf(mx, S[kt][r]);
       }
     }
   }
   mx = quad_max(mx);
+  const float msc = mx * SC2;
   float sum = 0.f;
 #pragma unroll
   for (int kt = 0; kt < SNT; ++kt)
     if (kt < kt_end) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { S[kt][r] = __expf(S[kt][r] - mx); sum += S[kt][r]; }
+      for (int r = 0; r < 4; ++r) { S[kt][r] = __builtin_amdgcn_exp2f(fmaf(S[kt][r], SC2, -msc)); sum += S[kt][r]; }
     }
   sum = quad_sum(sum);
   f32x4 O[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kt = 0; kt < SNT; ++kt)
-    if (kt < kt_end) accum_tile(O, Vs, kt, S[kt], fr, fg);
+  accum_all3<T>(O, Vh, Vl, S, 0, kt_end, fr, fg);
   if (q < qlim) {
     const float inv = 1.f / sum;
     T* orow = (T*)a.out_split + ((size_t)n * L + q) * (2 * (size_t)d) + h * 64;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, d, O[dt] * inv);
-    if (a.lse && fg == 0) a.lse[((size_t)n * a.H + h) * L + q] = mx + logf(sum);
+    if (a.lse && fg == 0) a.lse[((size_t)n * a.H + h) * L + q] = mx * SCALE + logf(sum);
   }
 }
 
 template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(SNT * 64) void attn32s_bwd_kernel(Attn32BwdArgs a) {
-  // Two LDS images (43.5 KiB: three workgroups per CU): K, V while the waves own query tiles (phase A: dQ), then Q, dO
-  // while they own key tiles (phase B: dK, dV).  The own rows live in registers in both phases.
-  __shared__ __attribute__((aligned(16))) float S0[SROWS * RS];
-  __shared__ __attribute__((aligned(16))) float S1[SROWS * RS];
-  __shared__ float lse_s[SROWS], del_s[SROWS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+__global__ __launch_bounds__(SNT * 64) void attn32t_bwd_kernel(Attn32BwdArgs a) {
+  // one set of four images (40 KiB, three workgroups per CU): K, V while the waves own query tiles (phase A: dQ), then Q, dO
+  // while they own key tiles (phase B: dK, dV); the own rows live in registers in both phases.  (Eight images in flight
+  // at once, 80 KiB, no restaging barrier: measured 20 % slower at 100 sequences, 4 % at 2191.)
+  __shared__ __attribute__((aligned(16))) char sm[4 * TIMG];
+  __shared__ float nlse_s[SROWS], del_s[SROWS];
+  char *I0h = sm, *I0l = sm + TIMG, *I1h = sm + 2 * TIMG, *I1l = sm + 3 * TIMG;
+  using v8 = typename Vec<T>::v8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
   const int n = blockIdx.y, h = blockIdx.x, L = a.L, d = a.H * 64;
   const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d, gld = 2 * (size_t)d;
   const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
   const T* gbase = (const T*)a.dout_split + (size_t)n * L * gld + h * 64;
-  stage_rows<T>(S0, base + d, lo, ld, L, tid, SNT * 64);          // K
-  stage_rows<T>(S1, base + 2 * d, lo, ld, L, tid, SNT * 64);      // V
+  stage_short<T>(I0h, I0l, base + d, lo, ld, L, wave, lane);          // K
+  stage_short<T>(I1h, I1l, base + 2 * d, lo, ld, L, wave, lane);      // V
   const size_t stat0 = ((size_t)n * a.H + h) * L;
   const int nt = (L + 15) >> 4;
   const int row = wave * 16 + fr, rc = row < L ? row : L - 1;     // own row: query in phase A, key in phase B
-  f32x4 Q[4], dO[4];
-  load_own<T>(Q, base + (size_t)rc * ld, lo, fg);
-  load_own<T>(dO, gbase + (size_t)rc * gld, d, fg);
-  // delta = rowsum(dO * O) of the own query row (O as a hi|lo pair)
-  float dl = 0.f;
+  v8 Qh[2], Ql[2], Gh[2], Gl[2], Kh[2], Kl[2], Vh[2], Vl[2];
+  load_own_pair<T>(Qh, Ql, base + (size_t)rc * ld, lo, fg);
+  load_own_pair<T>(Gh, Gl, gbase + (size_t)rc * gld, d, fg);
+  load_own_pair<T>(Kh, Kl, base + d + (size_t)rc * ld, lo, fg);
+  load_own_pair<T>(Vh, Vl, base + 2 * d + (size_t)rc * ld, lo, fg);
+  float dl = 0.f;       // delta = rowsum(dO * O) of the own query row
   {
-    const T* orow = (const T*)a.out_split + ((size_t)n * L + rc) * (2 * (size_t)d) + h * 64;
+    const T* orow = (const T*)a.out_split + ((size_t)n * L + rc) * gld + h * 64;
+    const T* grow = gbase + (size_t)rc * gld;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x4 o = load_pair4<T>(orow + 16 * t + 4 * fg, d);
+      const f32x4 o = load_pair4<T>(orow + 16 * t + 4 * fg, d), g = load_pair4<T>(grow + 16 * t + 4 * fg, d);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dl += o[e] * dO[t][e];
+      for (int e = 0; e < 4; ++e) dl += o[e] * g[e];
     }
     dl = quad_sum(dl);
   }
-  const float lse = a.lse[stat0 + rc];
-  if (fg == 0) { lse_s[row] = lse; del_s[row] = dl; }
+  const float nlse = -a.lse[stat0 + rc] * LOG2E;
+  if (fg == 0) { nlse_s[row] = nlse; del_s[row] = dl; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const bool active = wave < nt;
   T* orow = (T*)a.dqkv_split + ((size_t)n * L + rc) * ld + h * 64;
-  f32x4 K[4], V[4];
   // ---- phase A: own query tile -> dQ
   if (active) {
-    f32x4 dQ[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dQ[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int kt_end = CAUSAL ? wave + 1 : nt;
+    f32x4 dS[SNT];
 #pragma unroll
-    for (int kt = 0; kt < SNT; ++kt)
+    for (int kt = 0; kt < SNT; ++kt) {
+      dS[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (kt < kt_end) {
-        f32x4 S = mm_tile(S0, kt, Q, fr, fg);
-        const f32x4 dP = mm_tile(S1, kt, dO, fr, fg);
+        const f32x4 S = tile_rows3<T>(I0h, I0l, kt, Qh, Ql, fr, fg);
+        const f32x4 dP = tile_rows3<T>(I1h, I1l, kt, Gh, Gl, fr, fg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kk = 16 * kt + 4 * fg + r;
           const bool ok = kk < L && (!CAUSAL || kk <= row);
-          const float p = ok ? __expf(S[r] * SCALE - lse) : 0.f;
-          S[r] = p * (dP[r] - dl);
+          const float p = ok ? __builtin_amdgcn_exp2f(fmaf(S[r], SC2, nlse)) : 0.f;
+          dS[kt][r] = p * (dP[r] - dl);
         }
-        accum_tile(dQ, S0, kt, S, fr, fg);
       }
+    }
+    f32x4 dQ[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dQ[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accum_all3<T>(dQ, I0h, I0l, dS, 0, kt_end, fr, fg);
     if (row < L) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, lo, dQ[dt] * SCALE);
     }
-    load_own_lds(K, S0 + row * RS, fg);                    // own key row for phase B, before the images are replaced
-    load_own_lds(V, S1 + row * RS, fg);
   }
   __syncthreads();
-  stage_rows<T>(S0, base, lo, ld, L, tid, SNT * 64);       // Q
-  stage_rows<T>(S1, gbase, d, gld, L, tid, SNT * 64);      // dO
+  stage_short<T>(I0h, I0l, base, lo, ld, L, wave, lane);              // Q
+  stage_short<T>(I1h, I1l, gbase, d, gld, L, wave, lane);             // dO
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // ---- phase B: own key tile -> dK, dV
   if (active) {
-    f32x4 dK[4], dV[4];
+    const int qt_lo = CAUSAL ? wave : 0;
+    f32x4 P[SNT], dS[SNT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { dK[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int qt = 0; qt < SNT; ++qt)
-      if (qt < nt && (!CAUSAL || qt >= wave)) {
-        f32x4 S = mm_tile(S0, qt, K, fr, fg);            // lane: [key = fr][query = 16qt + 4fg + r]
-        f32x4 dP = mm_tile(S1, qt, V, fr, fg);
+    for (int qt = 0; qt < SNT; ++qt) {
+      P[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dS[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (qt < nt && qt >= qt_lo) {
+        const f32x4 S = tile_rows3<T>(I0h, I0l, qt, Kh, Kl, fr, fg);      // lane: [key = fr][query = 16qt + 4fg + r]
+        const f32x4 dP = tile_rows3<T>(I1h, I1l, qt, Vh, Vl, fr, fg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qq = 16 * qt + 4 * fg + r;
-          const bool ok = qq < L && row < L && (!CAUSAL || row <= qq);
-          const float p = ok ? __expf(S[r] * SCALE - lse_s[qq]) : 0.f;
-          S[r] = p;
-          dP[r] = p * (dP[r] - del_s[qq]);
+          const bool ok = qq < L && (!CAUSAL || row <= qq);
+          const float p = ok ? __builtin_amdgcn_exp2f(fmaf(S[r], SC2, nlse_s[qq])) : 0.f;
+          P[qt][r] = p;
+          dS[qt][r] = p * (dP[r] - del_s[qq]);
         }
-        accum_tile(dV, S1, qt, S, fr, fg);
-        accum_tile(dK, S0, qt, dP, fr, fg);
       }
+    }
+    f32x4 dK[4], dV[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dK[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    accum_all3<T>(dV, I1h, I1l, P, qt_lo, nt, fr, fg);
+    accum_all3<T>(dK, I0h, I0l, dS, qt_lo, nt, fr, fg);
     if (row < L) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        store_pair4<T>(orow + d + 16 * dt + 4 * fg, 3 * (size_t)d, dK[dt] * SCALE);
-        store_pair4<T>(orow + 2 * d + 16 * dt + 4 * fg, 3 * (size_t)d, dV[dt]);
+        store_pair4<T>(orow + d + 16 * dt + 4 * fg, lo, dK[dt] * SCALE);
+        store_pair4<T>(orow + 2 * d + 16 * dt + 4 * fg, lo, dV[dt]);
       }
     }
   }
@@ -658,8 +690,8 @@ template <typename T>
 static hipError_t fwd_t(const Attn32Args& a, hipStream_t s) {
   if (a.L <= SROWS) {
     dim3 grid(a.H, a.N), block(SNT * 64);
-    if (a.causal) hipLaunchKernelGGL((attn32s_fwd_kernel<T, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn32s_fwd_kernel<T, false>), grid, block, 0, s, a);
+    if (a.causal) hipLaunchKernelGGL((attn32t_fwd_kernel<T, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn32t_fwd_kernel<T, false>), grid, block, 0, s, a);
     return hipGetLastError();
   }
   const int lq = a.q_rows > 0 ? (a.q_rows < a.L ? a.q_rows : a.L) : a.L;
@@ -670,8 +702,8 @@ template <typename T>
 static hipError_t bwd_t(const Attn32BwdArgs& a, hipStream_t s) {
   if (a.L <= SROWS) {
     dim3 grid(a.H, a.N), block(SNT * 64);
-    if (a.causal) hipLaunchKernelGGL((attn32s_bwd_kernel<T, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn32s_bwd_kernel<T, false>), grid, block, 0, s, a);
+    if (a.causal) hipLaunchKernelGGL((attn32t_bwd_kernel<T, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn32t_bwd_kernel<T, false>), grid, block, 0, s, a);
     return hipGetLastError();
   }
   if (a.L > 8192) return hipErrorInvalidValue;       // the dK/dV kernel keeps lse and delta of a whole sequence in LDS
