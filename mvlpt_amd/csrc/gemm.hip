@@ -181,7 +181,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
 // next tile are in flight while the current tile finishes and its epilogue is stored), so the short-K GEMMs of
 // this path (K = 768 / 512) do not pay a load bubble per tile.
 template <typename T, int EPI, int BM_, int BN_, int NW, int NS>
-__global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2) void gemm_bt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using v8 = typename Vec<T>::v8;
   constexpr int BN = BN_;
@@ -276,8 +276,10 @@ __global__ __launch_bounds__(NW * 64, NW == 2 ? 1 : 2) void gemm_bt_kernel(GemmA
   auto wait_stage = [&](int younger, bool skip_stores) {
     if (younger >= 2 && NS >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
     else if (younger >= 1 && NS >= 3) {
-      if (skip_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + ST_MIN_) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      if constexpr (LOADS + ST_MIN_ <= 63) {
+        if (skip_stores) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + ST_MIN_) : "memory"); return; }
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   wait_stage(n_issued - 1, false);
@@ -603,6 +605,8 @@ static GemmArgs row_slice(const GemmArgs& g, int m_lo, int rows) {
 
 template <typename T, int EPI>
 static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb, int* tile_m, int* tile_n) {
+  // (256x256 with FOUR waves of 256x64 — 17 % less LDS-read traffic per FLOP, one wave per SIMD — was measured 17-36 % slower
+  // than the eight-wave kernel: 8192^3 1.09 vs 1.31 PF; nothing hides a wave's own LDS-DMA issue and ds_read latency.)
   // geometry by tile count: 256x256 (128x64 wave tiles, least LDS-DMA / LDS-read traffic per FLOP) needs >= 4 full
   // rounds of 256 resident workgroups to amortise its tail; 256x128 needs >= 1.5 rounds; otherwise 128x128.
   const long t128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
