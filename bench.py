@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--multitask", action="store_true",
                     help="ELEVATER-style multitask batch: per-task logit mask + soft labels (needs a multitask class list: 2191 / 1151 classes)")
     ap.add_argument("--grad-precision", default="split_grad", choices=["split_grad", "fast"],
-                    help="split_grad (default): hi+lo operand pairs + fp32 attention in towers that carry a gradient (prompt "
+                    help="split_grad (default): hi+lo operand pairs (GEMMs and attention) in towers that carry a gradient (prompt "
                          "gradients within 1e-3 of the fp32 CPU path); fast: single 16-bit operands everywhere (~4e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")

@@ -63,7 +63,7 @@ def get_cfg_default() -> CfgNode:
         COCOOP=CN(N_CTX=0, CTX_INIT="", PREC="fp16"),
         # not in the reference: MFMA input type of the MI355X towers
         COMPUTE_DTYPE="fp16",
-        # not in the reference: "split_grad" (default: hi+lo operand pairs + fp32 attention in towers that carry a
+        # not in the reference: "split_grad" (default: hi+lo operand pairs (GEMMs and attention) in towers that carry a
         # gradient: prompt gradients within 1e-3 of the fp32 CPU path) | "fast" (single 16-bit operands, ~4e-3)
         GRAD_PRECISION="split_grad",
         # not in the reference: compute the NEXT batch's image features underneath the current text-tower backward when

@@ -70,7 +70,7 @@ struct TowerW { int width = 0, layers = 0, heads = 0; std::vector<Block> blocks;
 
 struct TowerState {
   bool valid = false, saved = false, causal = false;
-  bool exact = false;                    // split-precision operands + fp32 attention (see DESIGN.md "Precision modes")
+  bool exact = false;                    // split-precision operands + pair-product attention (see DESIGN.md "Precision modes")
   int N = 0, L = 0, d = 0, H = 0, layers = 0;
   std::vector<float*> x;                 // 2*layers+1 entries (all equal when !saved)
   std::vector<void*> qkv, attn, u;       // per layer (all equal when !saved)
@@ -225,7 +225,7 @@ void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool s
   st.valid = true;
 }
 
-// fp32 attention core of the split-precision mode: qkv32 [T,3d] -> O as a hi|lo pair [T,2d]
+// attention core of the split-precision mode: qkv pair [T,6d] -> O as a hi|lo pair [T,2d]
 int attn32_fwd(Engine* E, TowerState& st, int l, int q_rows, hipStream_t s) {
   Attn32Args a{st.qkv[l], st.attn[l], st.saved ? st.lse[l] : nullptr, st.N, st.L, st.H, st.causal ? 1 : 0, q_rows};
   const double rows = q_rows > 0 ? (double)q_rows : (double)st.L;
@@ -591,7 +591,7 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
     float* xmid = save ? E->xcm32 : E->xc32;     // kept for the backward: LN2 input ...
     float* xout = save ? E->xco32 : E->xc32;     // ... and ln_post input
     E->v_cls_last = save;
-    const int xs = st.exact ? 1 : 0;      // split-precision operands (hi|lo pairs, twice the columns) + fp32 attention
+    const int xs = st.exact ? 1 : 0;      // split-precision operands (hi|lo pairs, twice the columns) + pair-product attention
     HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dv, s, xs));
     HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dv, dv, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
     if (xs) {
@@ -649,7 +649,7 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
     HIPCHK(E, ln_bwd(E, E->dhc32, DT_F32, E->xcm32, nullptr, 1, Bk.ln2, E->dxc32, E->dxc32, E->dxc16, B, dv, s, -1, xs));
     HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, E->dxc16, Bk.o.wt, B, dv, dv, nullptr, nullptr, nullptr, E->dOc16, nullptr, s, -1, xs));
     if (xs) {
-      // fp32 attention backward at full width on a dO that is zero except for the CLS rows
+      // split-precision attention backward at full width on a dO that is zero except for the CLS rows
       { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 4.0);
         HIPCHK(E, launch_zero(st.dO16, T * dv * 4, s));
         HIPCHK(E, launch_copy_rows_strided(E->dOc16, st.dO16, B, (size_t)dv * 4, (size_t)Lv * dv * 4, dv * 4, s)); }

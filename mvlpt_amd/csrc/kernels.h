@@ -92,7 +92,7 @@ hipError_t launch_attn_bwd_cls(int dtype, const void* qkv, const void* o_cls, co
 hipError_t launch_attn_fwd_stream(int dtype, const AttnArgs& a, hipStream_t s);
 hipError_t launch_attn_bwd_stream(int dtype, const AttnBwdArgs& a, hipStream_t s);
 
-// ---------------------------------------------------------------- fp32 attention (attention32.hip), any L
+// ---------------------------------------------------------------- split-precision attention (attention32.hip), any L
 // Split-precision mode of the towers that carry a gradient: every operand is a 16-bit hi|lo pair [rows, 2*cols]
 // (hi = round16(x), lo = round16(x - hi)), products keep hi*hi + hi*lo + lo*hi on the 16-bit MFMA (fp32 accumulation);
 // the outputs are pairs again: directly the `a_split` A operand of the next GEMM.

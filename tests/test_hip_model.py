@@ -4,7 +4,7 @@ golden vectors produced by the REAL reference on its CPU fp32 path (oracle/make_
 
 Tolerances = BASELINE.json north_star ("logits/grads within 1e-3 fp16 rel-tol", "logits within 1e-3 of CPU reference"),
 default engine mode (fp16 MFMA inputs, fp32 accumulation; towers that carry a gradient run with split hi+lo operands and
-fp32 attention — MVLPT_PREC_SPLIT_GRAD), integer tables bit-exact:
+pair-product attention — MVLPT_PREC_SPLIT_GRAD), integer tables bit-exact:
   logits   : max|a-b| <= 1e-3 * max(1, max|ref|)  AND  element-wise allclose(rtol = atol = 1e-3)
   features : max|a-b| <= 1e-3 * max|ref|              (tower outputs before the head)
   loss     : |a-b|    <= 1e-3

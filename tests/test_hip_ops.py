@@ -168,7 +168,7 @@ def test_gemm_race_screen(M, N, K, epi):
 
 
 # ---------------------------------------------------------------------------------------------- split-precision mode
-# (hi+lo 16-bit operand pairs for the GEMM A operand, fp32 attention: DESIGN.md "Precision modes").  The weights are
+# (hi+lo 16-bit operand pairs for the GEMM A operand and in attention: DESIGN.md "Precision modes").  The weights are
 # exactly 16-bit (as CLIP checkpoints are); the activations are arbitrary fp32: the results must match an fp32 matmul to
 # ~2^-21 relative, i.e. three orders of magnitude better than the single-operand kernels above.
 SPLIT_TOL = {torch.float16: 3e-6, torch.bfloat16: 6e-5}    # pair = 22 / 16 significant bits
@@ -236,7 +236,7 @@ def test_layernorm_split_outputs(dtype, d, rows):
 @pytest.mark.parametrize("L,causal", [(5, False), (5, True), (24, True), (64, True), (65, False), (77, True), (197, False), (205, False),
                                       (261, False), (581, False)])
 def test_attention32_fwd_bwd(L, causal):
-    """fp32 attention core of the split-precision mode: fp32 in, f32 MFMA, pair outputs — fp32-level agreement with the oracle."""
+    """Attention core of the split-precision mode (pair operands, three-term products): fp32-level agreement with the oracle."""
     E = _eng()
     N, H = 3, 2
     d = H * 64
