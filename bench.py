@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--cut", action="store_true", help="CUT_CONTEXTLEN text length instead of 77")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--trim-eot", action="store_true", help="evaluate the causal text tower only up to max(EOT) (exact; off by default)")
+    ap.add_argument("--no-trim-extra", action="store_true", help="skip the extra untimed-for-the-headline pass that reports the --trim-eot rate")
     ap.add_argument("--no-step-pipelining", action="store_true",
                     help="do not compute the next batch's image features underneath the current backward")
     ap.add_argument("--shard-text", action="store_true", help="class-shard the text tower over the ranks (many-class configs)")
@@ -255,6 +256,35 @@ def main():
     elapsed = mark["t1"] - mark["t0"]
     stats = eng.profile_end() if timing else {}
     elapsed = D.all_reduce_max(elapsed, dev)
+    # Reported beside the headline, never AS the headline: the same loop with the causal text tower evaluated only up to
+    # max(EOT) (positions after EOT can reach neither a logit nor a gradient; exact, tests/test_hip_model.py::
+    # test_trim_to_eot_is_exact).  `value` keeps all L positions, as the reference computes them.
+    trim_line = None
+    if n_ctx and not args.trim_eot and not args.cut and not args.no_trim_extra and K >= 8:
+        trainer.model.trim_text_to_eot = True
+        W2, K2 = 4, min(K, 16)
+        dm.train_loader_x = _CyclingLoader(dm.train_loader_x.batches, W2 + K2 + 1)
+        trainer.train_loader_x = dm.train_loader_x
+        mark2 = {}
+
+        def hook2(i):
+            if i == W2:
+                fence()
+                mark2["t0"] = time.perf_counter()
+            if i == W2 + K2:
+                fence()
+                mark2["t1"] = time.perf_counter()
+                return False
+            return True
+
+        trainer.batch_hook = hook2
+        trainer.run_epoch()
+        trainer.batch_hook = None
+        e2 = D.all_reduce_max(mark2["t1"] - mark2["t0"], dev)
+        trainer.model.trim_text_to_eot = False
+        trim_line = {"value": round(args.batch * world * K2 / e2, 2), "ms_per_step": round(1e3 * e2 / K2, 3), "steps": K2,
+                     "text_positions_evaluated": int(trainer.model.prompt_learner.max_eot + 1),
+                     "note": "same loop, causal text tower evaluated up to max(EOT) only (exact: later positions reach no logit and no gradient); not the headline"}
     # Untimed extra pass: the same step with the two towers serialized on one stream and no cross-step prefetch, so each
     # GEMM launch has the chip to itself.  In the timed region the text tower runs on a second stream underneath the
     # image tower; concurrent kernels stretch each other's durations, which inflates per-launch times (they then sum
@@ -337,6 +367,8 @@ def main():
             att = (args.batch * arch.vision_layers * 4 * (1 + n_vpt + arch.grid ** 2) ** 2 * arch.vision_width * (3 if n_vpt else 1)
                    + (args.classes * arch.transformer_layers * 2 * L_text ** 2 * arch.transformer_width * 3 if n_ctx else 0))
             line["step_mfma_fraction_executed"] = round((g["flops_executed"] / n_sampled + att) / (elapsed / K) / (MFMA_PEAK_TFLOPS * 1e12), 4)
+        if trim_line is not None:
+            line["text_trimmed_to_eot"] = trim_line
         if world == 1 and not args.no_cpu_baseline and args.method == "coop" and pre is not None:
             line["cpu_baseline"] = cpu_baseline_images_per_sec(arch, sd, args.classes, L_text, n_ctx, pre)
         print(json.dumps(line), flush=True)
