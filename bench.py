@@ -106,6 +106,60 @@ def cpu_baseline_images_per_sec(arch, sd, C, L, n_ctx, pre, B_cpu=64, steps=3):
                       f"{steps} timed full steps of {t:.2f} s (image tower forward, text tower forward+backward, head)"}
 
 
+class _ClockSampler:
+    """Engine clock and board power while the timed region runs, from the amdgpu hwmon files (freq1_input = sclk in Hz,
+    power1_input in uW), polled every 50 ms on a host thread.  Under sustained MFMA load the MI355X sits near its 1400 W
+    cap and sclk drops from the nominal 2400 MHz (the clock MFMA_PEAK_TFLOPS is quoted at) to 1.7-2.0 GHz: the bench
+    line reports the measured clock so that the roofline fraction can also be read against the peak at THAT clock."""
+    NOMINAL_MHZ = 2400.0
+
+    def __init__(self):
+        import glob
+        self.cards = []
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            if os.path.isfile(h + "/freq1_input") and os.path.isfile(h + "/power1_input"):
+                self.cards.append(h)
+        self.samples = {h: [] for h in self.cards}
+        self._stop, self._thread = False, None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop:
+            for h in self.cards:
+                f, p = self._read(h + "/freq1_input"), self._read(h + "/power1_input")
+                if f is not None and p is not None:
+                    self.samples[h].append((f * 1e-6, p * 1e-6))
+            time.sleep(0.05)
+
+    def start(self):
+        if self.cards:
+            import threading
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+        best = None
+        for h, v in self.samples.items():            # several boards may be visible in sysfs: the busy one is ours
+            if len(v) >= 2:
+                mhz, w = sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v)
+                if best is None or w > best["power_w_avg"]:
+                    cap = self._read(h + "/power1_cap")
+                    best = {"sclk_mhz_avg": round(mhz, 1), "sclk_mhz_min": round(min(x[0] for x in v), 1), "power_w_avg": round(w, 1),
+                            "power_cap_w": round(cap * 1e-6, 1) if cap else None, "samples": len(v), "nominal_sclk_mhz": self.NOMINAL_MHZ,
+                            "source": "amdgpu hwmon freq1_input / power1_input, 50 ms polling during the timed region"}
+        return best
+
+
 class _CyclingLoader:
     """`total` batches cycling over a few resident synthetic batches (what Dassl's DataLoader is to TrainerX.run_epoch)."""
 
@@ -236,15 +290,21 @@ def main():
         D.barrier()
         torch.cuda.synchronize()
 
+    clk = _ClockSampler() if rank == 0 else None
+
     def hook(i):
         if i == W:
             fence()
             if timing:
                 eng.profile_begin(all_kernels=args.all_kernel_timing)
+            if clk is not None:
+                clk.start()
             mark["t0"] = time.perf_counter()
         if i == W + K:
             fence()
             mark["t1"] = time.perf_counter()
+            if clk is not None:
+                mark["clock"] = clk.stop()
             return False
         if timing and i >= W:
             eng.profile_pause((i - W) % sample_every != 0)
@@ -329,6 +389,11 @@ def main():
             "step_mfma_fraction": round(ips / world * gf_img / (MFMA_PEAK_TFLOPS * 1e3), 4),
             "algorithmic_gflop_per_image": round(gf_img, 3),
         }
+        clock = mark.get("clock")
+        if clock:
+            line["clock"] = clock
+            sustained = MFMA_PEAK_TFLOPS * clock["sclk_mhz_avg"] / _ClockSampler.NOMINAL_MHZ
+            line["step_mfma_fraction_at_measured_clock"] = round(ips / world * gf_img / (sustained * 1e3), 4)
         traffic = None
         if os.path.isfile(TRAFFIC_FILE) and is_headline:
             with open(TRAFFIC_FILE) as f:
@@ -353,6 +418,9 @@ def main():
                                 "algorithmic_bytes_per_launch": int(g["bytes"] / g["launches"]),
                                 "concurrency": "timed region: text tower on a 2nd stream and the next batch's image tower on a 3rd overlap; achieved = FLOPs / union of the launch intervals",
                                 "note": "achieved / frac charge ALGORITHMIC FLOPs (2MNK per linear); launches with split-precision operands execute twice that (achieved_executed)"}
+            if clock:
+                line["roofline"]["peak_at_measured_clock"] = round(sustained, 1)
+                line["roofline"]["frac_at_measured_clock"] = round(tf / sustained, 4)
             if "gemm_bt" in stats_serial:
                 gs = stats_serial["gemm_bt"]
                 tfs = gs["flops"] / (gs["ms"] * 1e-3) / 1e12

@@ -569,6 +569,7 @@ static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hi
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (getenv("MVLPT_DBG_CUS")) cus = atoi(getenv("MVLPT_DBG_CUS"));
   }
   const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
   const int resident = cus * wg_per_cu;
