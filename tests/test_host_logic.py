@@ -138,3 +138,33 @@ def test_init_weights_drop_class_buffers_and_mismatched_shapes(tmp_path):
     load_pretrained_weights(dst.prompt_learner, str(path))
     assert torch.equal(dst.prompt_learner.ctx.data, sd["ctx"])
     assert torch.equal(dst.prompt_learner.token_suffix, before) and dst.prompt_learner.token_suffix.shape[0] == 3
+
+
+def test_bench_clock_sampler_reads_hwmon(tmp_path, monkeypatch):
+    """bench.py's clock / power sampler: picks the busy board among the hwmon directories, averages MHz and W; no board -> None."""
+    import glob as _glob
+    import importlib.util
+    import os
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dirs = []
+    for i, (hz, uw) in enumerate([(158e6, 250e6), (2010e6, 1300e6)]):
+        d = tmp_path / f"card{i}" / "device" / "hwmon" / f"hwmon{i}"
+        d.mkdir(parents=True)
+        (d / "freq1_input").write_text(f"{int(hz)}\n")
+        (d / "power1_input").write_text(f"{int(uw)}\n")
+        (d / "power1_cap").write_text("1400000000\n")
+        dirs.append(str(d))
+    monkeypatch.setattr(_glob, "glob", lambda pat: dirs if "hwmon" in pat else [])
+    s = bench._ClockSampler()
+    assert s.cards == sorted(dirs)
+    s.start()
+    time.sleep(0.25)
+    out = s.stop()
+    assert out["sclk_mhz_avg"] == 2010.0 and out["power_w_avg"] == 1300.0 and out["power_cap_w"] == 1400.0 and out["samples"] >= 2
+    monkeypatch.setattr(_glob, "glob", lambda pat: [])
+    s = bench._ClockSampler()
+    s.start()
+    assert s.stop() is None
