@@ -233,8 +233,9 @@ def test_layernorm_split_outputs(dtype, d, rows):
     assert relerr(E.join_pair(dx2), dx32) < SPLIT_TOL[dtype]          # the pair carries the fp32 result
 
 
-@pytest.mark.parametrize("L,causal", [(5, False), (5, True), (24, True), (64, True), (65, False), (77, True), (197, False), (205, False),
-                                      (261, False), (581, False)])
+@pytest.mark.parametrize("L,causal", [(5, False), (5, True), (1, False), (16, True), (17, False), (24, True), (64, True), (65, False), (77, True),
+                                      (80, True), (80, False), (81, True), (81, False), (128, False), (129, True), (197, False), (205, False),
+                                      (256, False), (257, True), (261, False), (581, False)])
 def test_attention32_fwd_bwd(L, causal):
     """Attention core of the split-precision mode (pair operands, three-term products): fp32-level agreement with the oracle."""
     E = _eng()
@@ -256,10 +257,14 @@ def test_attention32_fwd_bwd(L, causal):
     dqkv_ref = torch.cat([t.permute(0, 2, 1, 3).reshape(N * L, d) for t in (dq, dk, dv)], dim=-1)
     dqkv = E.join_pair(E.op_attention32_bwd(qkv.cuda(), out2, dout.cuda(), lse, N, L, H, causal))
     for i, nm in enumerate("qkv"):
-        e = relerr(dqkv[:, i * d:(i + 1) * d], dqkv_ref[:, i * d:(i + 1) * d])
+        got_i, ref_i = dqkv[:, i * d:(i + 1) * d].cpu(), dqkv_ref[:, i * d:(i + 1) * d]
+        if float(ref_i.abs().max()) < 1e-6:          # L = 1: softmax over one key, dQ = dK = 0 exactly in the reference
+            assert float(got_i.abs().max()) < 1e-5, f"d{nm}"
+            continue
+        e = relerr(got_i, ref_i)
         assert e < 1e-5, f"d{nm}: {e}"
     # CLS-only forward (last image block): only query 0 of every sequence is produced, the rest stays untouched
-    if not causal:
+    if not causal and L > 1:
         o1, _ = E.op_attention32_fwd(qkv.cuda(), N, L, H, causal, q_rows=1)
         got = E.join_pair(o1).cpu().reshape(N, L, d)
         assert relerr(got[:, 0], o_ref.reshape(N, L, d)[:, 0]) < 5e-6 and float(got[:, 1:].abs().max()) == 0.0

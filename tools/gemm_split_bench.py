@@ -1,4 +1,4 @@
-"""Time the split-operand GEMMs (A = hi|lo pair) on the step's shapes, shared-B stage layout vs plain (MVLPT_GEMM_SB=0/1). GPU box only."""
+"""Time the split-operand GEMMs (A = hi|lo pair, 2K MFMA depth) on the step's shapes through the C ABI. GPU box only."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
