@@ -37,6 +37,9 @@ constexpr int TR_MAX = 2048;
 #ifndef MVLPT_NS2_MODE
 #define MVLPT_NS2_MODE 1
 #endif
+#ifndef MVLPT_FRAG_DEPTH
+#define MVLPT_FRAG_DEPTH 2
+#endif
 #ifndef MVLPT_NS2_POS
 #define MVLPT_NS2_POS (GROUPS / 2 - 2)   // after the 3rd of 8 MFMA groups; later positions expose the DMA latency (measured)
 #endif
@@ -309,11 +312,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
       MVLPT_TR(1);
       if (dma_first) { issued = issue(); MVLPT_TR(2); }
       const char* base = smem + slot * STAGE;
-      // Register-double-buffered fragment pipeline: the ds_reads of MFMA group s+1 (two A fragments, plus the four
-      // B fragments when the k-step changes) are issued BEFORE the 8 MFMAs of group s, so hipcc's counted lgkmcnt
-      // lets the LDS latency run under the matrix pipe instead of in front of every 8-MFMA burst.
+      // Register-buffered fragment pipeline: the ds_reads of MFMA group s+1 (two A fragments, plus the four B fragments
+      // when the k-step changes) are issued BEFORE the 8 MFMAs of group s, so hipcc's counted lgkmcnt lets the LDS
+      // latency run under the matrix pipe instead of in front of every 8-MFMA burst.  (-DMVLPT_FRAG_DEPTH=3, two groups
+      // of lookahead, measured 5 % SLOWER on long-K shapes: 8192^3 1.23 vs 1.30 PF in the same run.)
       constexpr int PAIRS = WMF / 2, GROUPS = 2 * PAIRS;
-      v8 bfr[2][4], afr[2][2];
+      constexpr int DEPTH = MVLPT_FRAG_DEPTH;          // 2 = double-buffered (one group ahead), 3 = two groups ahead
+      v8 bfr[2][4], afr[DEPTH][2];
       auto load_b = [&](int ks, v8 (&bf)[4]) {
         const int c = ks ? c1 : c0;
 #pragma unroll
@@ -325,23 +330,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
         for (int i = 0; i < 2; ++i) af[i] = *(const v8*)(base + a_off + (pair * 2 + i) * 2048 + c);
       };
       load_b(0, bfr[0]);
-      load_a2(0, 0, afr[0]);
+#pragma unroll
+      for (int p0 = 0; p0 < DEPTH - 1; ++p0) load_a2(p0 / PAIRS, p0 % PAIRS, afr[p0]);
 #pragma unroll
       for (int sg = 0; sg < GROUPS; ++sg) {
-        const int ks = sg / PAIRS, pair = sg % PAIRS, cur = sg & 1;
-        // The prefetch reads of group sg+1 are placed AFTER the first MFMA of group sg: hipcc waits with lgkmcnt(0)
-        // in front of the first MFMA that needs LDS data, and with the reads in front of it that wait would also
-        // cover the reads just issued (a full LDS round trip in front of every other group).
+        const int ks = sg / PAIRS, pair = sg % PAIRS, cur = sg % DEPTH;
+        // The prefetch reads are placed AFTER the first MFMA of group sg: hipcc waits in front of the first MFMA that
+        // needs LDS data, and with the reads in front of it that wait would also cover the reads just issued.
         __builtin_amdgcn_sched_barrier(0);
         {
           const int ai = pair * 2;
           acc[ai >> 2][ai & 3][0] = mfma16<T>(bfr[ks & 1][0], afr[cur][0], acc[ai >> 2][ai & 3][0]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (sg + 1 < GROUPS) {
-          const int nks = (sg + 1) / PAIRS, npair = (sg + 1) % PAIRS;
+        if (sg + DEPTH - 1 < GROUPS) {
+          const int n = sg + DEPTH - 1, nks = n / PAIRS, npair = n % PAIRS;
           if (npair == 0) load_b(nks, bfr[nks & 1]);
-          load_a2(nks, npair, afr[cur ^ 1]);
+          load_a2(nks, npair, afr[n % DEPTH]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
