@@ -26,6 +26,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak of one MI355X (MI355X_MICROARCH.md)
+# What a register-only MFMA loop (no LDS, no memory traffic) sustains on pseudo-random fp16 operands: the board throttles to
+# ~1.9 GHz at ~1.3 kW (tools/mfma_peak.hip, profiles/r02_power_clock_mfma_only.txt; 2 456 TF/s with constant operands).
+# Annotation only: `peak` and `frac` stay on the nominal figure.
+MFMA_MEASURED_CEILING_TFLOPS = 1883.0
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "gemm_hbm_traffic.json")   # written from rocprofv3 --pmc passes
 
 
@@ -418,6 +422,9 @@ def main():
                                 "algorithmic_bytes_per_launch": int(g["bytes"] / g["launches"]),
                                 "concurrency": "timed region: text tower on a 2nd stream and the next batch's image tower on a 3rd overlap; achieved = FLOPs / union of the launch intervals",
                                 "note": "achieved / frac charge ALGORITHMIC FLOPs (2MNK per linear); launches with split-precision operands execute twice that (achieved_executed)"}
+            line["roofline"]["measured_mfma_only_ceiling"] = {"value": MFMA_MEASURED_CEILING_TFLOPS, "unit": "TFLOP/s",
+                                                              "frac": round(tf / MFMA_MEASURED_CEILING_TFLOPS, 4),
+                                                              "source": "profiles/r02_power_clock_mfma_only.txt (register-only MFMA loop, pseudo-random fp16 operands, 1.9 GHz at 1.3 kW)"}
             if clock:
                 line["roofline"]["peak_at_measured_clock"] = round(sustained, 1)
                 line["roofline"]["frac_at_measured_clock"] = round(tf / sustained, 4)
