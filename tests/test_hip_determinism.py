@@ -47,3 +47,43 @@ def test_text_tower_is_bit_stable_under_a_concurrent_image_tower(precision, imag
                 assert torch.equal(f, f0), f"text features changed under a concurrent image tower (save={save}, iteration {it})"
                 if save:
                     assert torch.equal(g, g0), f"context gradient changed under a concurrent image tower (iteration {it})"
+
+
+@pytest.mark.parametrize("image_batch", [16, 48])
+def test_image_tower_with_backward_is_bit_stable_under_a_concurrent_text_tower(image_batch):
+    """The mirror case (VPT / UPT steps): the split-precision image tower, forward + backward (pair-operand GEMMs, streamed
+    three-term attention with its two-phase backward), while the text tower of the same engine runs on another stream."""
+    from mvlpt_amd.class_prompts import load_class_prompts
+    from mvlpt_amd.config import get_cfg_default
+    from mvlpt_amd.model import CustomCLIP, FrozenCLIP
+    from mvlpt_amd.weights import ARCHS, make_state_dict
+    arch = ARCHS["ViT-B/16"]
+    cfg = get_cfg_default()
+    cfg.TRAINER.MVLPT.COOP.N_CTX = 16
+    pre, C = load_class_prompts("caltech101", 16)
+    torch.manual_seed(0)
+    model = CustomCLIP(cfg, ["c"] * C, FrozenCLIP(make_state_dict(arch, 3), "fp16", precision="split_grad"), pretokenized=pre).cuda()
+    pl, eng = model.prompt_learner, model.engine
+    ctx = pl.ctx.detach()
+    n, dv = 8, arch.vision_width
+    vpt = torch.randn(n, dv, device="cuda") * 0.05
+    deep = torch.randn(arch.vision_layers - 1, n, dv, device="cuda") * 0.05
+    x = torch.randn(image_batch, 3, 224, 224, device="cuda").half()
+    dfeat = torch.randn(image_batch, arch.embed_dim, device="cuda") * 1e-3
+
+    def image():
+        f = eng.image_fwd(x, vpt, deep, save_for_bwd=True).clone()
+        dv_, dd_ = eng.image_bwd(dfeat)
+        return f, dv_.clone(), dd_.clone()
+
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        f0, a0, b0 = image()
+        torch.cuda.synchronize()
+        for it in range(15):
+            with torch.cuda.stream(side):
+                eng.text_fwd(pl.token_prefix, pl.token_suffix, ctx, pl.layout, pl.eot, save_for_bwd=False)
+            f, a, b = image()
+            torch.cuda.synchronize()
+            assert torch.equal(f, f0), f"image features changed under a concurrent text tower (iteration {it})"
+            assert torch.equal(a, a0) and torch.equal(b, b0), f"visual-prompt gradients changed under a concurrent text tower (iteration {it})"
