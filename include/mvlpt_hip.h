@@ -42,10 +42,12 @@ typedef struct MvlptArch {
  * All modes: 16-bit MFMA operands, fp32 accumulation, fp32 residual stream / LayerNorm / softmax / cross-entropy.
  *   MVLPT_PREC_FAST       single 16-bit operands everywhere (prompt gradients within ~4e-3 of the fp32 CPU path)
  *   MVLPT_PREC_SPLIT_GRAD default: a tower whose forward is saved for a backward runs with SPLIT operands — every GEMM A
- *                         operand is a hi+lo pair of 16-bit values (~22 bits; the frozen weights are exactly 16-bit), and the
- *                         attention core runs in fp32 — so prompt gradients match the fp32 CPU path to 1e-3; forward-only
- *                         towers (e.g. the image tower under CoOp, inference) stay in the fast mode
- *   MVLPT_PREC_SPLIT_ALL  split operands in every tower (PREC = "fp32") */
+ *                         operand is hi = round16(x) plus its rounding residual as one e5m2 byte (the "mixed pair" below: the
+ *                         residual term runs on the fp8 MFMA against an e4m3 copy of the frozen weight, ~2^-16 of the value),
+ *                         the attention core takes 16-bit hi+lo pairs with three-term products — so prompt gradients match the
+ *                         fp32 CPU path to 1e-3; forward-only towers (e.g. the image tower under CoOp, inference) stay fast.
+ *                         Environment MVLPT_SPLIT_LO8=0 selects 16-bit hi+lo pairs for the GEMMs as well (twice the matrix time)
+ *   MVLPT_PREC_SPLIT_ALL  split operands in every tower, 16-bit hi+lo pairs (~22 bits) everywhere (PREC = "fp32") */
 enum { MVLPT_PREC_FAST = 0, MVLPT_PREC_SPLIT_GRAD = 1, MVLPT_PREC_SPLIT_ALL = 2 };
 
 int mvlpt_create(const MvlptArch* arch, void** handle);
@@ -122,6 +124,27 @@ int mvlpt_op_attention32_fwd(int dtype, const void* qkv, void* out, float* lse, 
                              mvlpt_stream_t stream);
 int mvlpt_op_attention32_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                              void* dqkv, int N, int L, int H, int causal, mvlpt_stream_t stream);
+/* ---- mixed pair: the default split format of MVLPT_PREC_SPLIT_GRAD.  A row holds [hi (cols x 16 bit) | residual bytes (cols) |
+ * unused] at the pair's pitch of 2*cols 16-bit elements: hi = round16(x), byte = e5m2((x - hi) * 2^10) (bf16: 2^7).  A GEMM with
+ * such an A operand multiplies hi with the 16-bit weight on v_mfma_f32_16x16x32 and the residual bytes with the weight's e4m3
+ * copy on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the rate): 1.5x the matrix time of a single-operand GEMM instead of 2x.
+ * pack_weight_mixed: w32 [rows, cols] fp32 -> out [R, 3K/2] 16-bit elements = [W16 (K) | e4m3(W * 2^*w8_exp) (K bytes)] with
+ * (R, K) = (rows, cols), or (cols, rows) when `transposed`; synchronises the stream (the exponent is returned to the host).
+ * gemm_mixed: epilogues 2 / 4 (fp32 outputs), 7 (16-bit pair for the attention core), 5 / 6 (mixed-pair outputs). K % 128 == 0. */
+int mvlpt_op_pack_weight_mixed(int dtype, const float* w32, int rows, int cols, int transposed, void* out, int* w8_exp,
+                               mvlpt_stream_t stream);
+int mvlpt_op_gemm_mixed(int dtype, int epi, const void* A, const void* Bt, int ldb, int w8_exp, int M, int N, int K, const float* bias,
+                        const void* aux, const float* resid, void* out, void* out2, mvlpt_stream_t stream);
+int mvlpt_op_cast_mixed(int dtype, const float* in, void* out, int64_t rows, int d, mvlpt_stream_t stream);
+int mvlpt_op_layernorm_fwd_mixed(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
+                                 mvlpt_stream_t stream);
+int mvlpt_op_layernorm_bwd_mixed(int dtype, const void* dy, const float* x, const float* gamma, const float* resid, float* out32,
+                                 void* out16, int rows, int d, mvlpt_stream_t stream);
+/* attention core with 16-bit pair inputs (qkv, dout) and mixed-pair tensors on the GEMM side (out; dqkv) */
+int mvlpt_op_attention32_fwd_mixed(int dtype, const void* qkv, void* out, float* lse, int N, int L, int H, int causal, int q_rows,
+                                   mvlpt_stream_t stream);
+int mvlpt_op_attention32_bwd_mixed(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                                   void* dqkv, int N, int L, int H, int causal, mvlpt_stream_t stream);
 int mvlpt_op_layernorm_fwd(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
                            mvlpt_stream_t stream);
 int mvlpt_op_layernorm_bwd(int dtype, const void* dy, const float* x, const float* gamma, const float* resid, float* out32,

@@ -63,6 +63,13 @@ SIGNATURES = {
     "mvlpt_op_layernorm_bwd_split": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mvlpt_op_attention32_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mvlpt_op_attention32_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mvlpt_op_pack_weight_mixed": (_i, [_i, _vp, _i, _i, _i, _vp, C.POINTER(C.c_int), _vp]),
+    "mvlpt_op_gemm_mixed": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvlpt_op_cast_mixed": (_i, [_i, _vp, _vp, C.c_int64, _i, _vp]),
+    "mvlpt_op_layernorm_fwd_mixed": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mvlpt_op_layernorm_bwd_mixed": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mvlpt_op_attention32_fwd_mixed": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mvlpt_op_attention32_bwd_mixed": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvlpt_op_layernorm_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mvlpt_op_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mvlpt_op_attention_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

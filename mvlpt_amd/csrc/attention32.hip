@@ -40,6 +40,31 @@ __device__ __forceinline__ void store_pair4(T* p, size_t lo_off, f32x4 v) {
   *(typename Vec<T>::v4*)p = hi;
   *(typename Vec<T>::v4*)(p + lo_off) = lo;
 }
+// ... or, for a tensor whose only other reader is a GEMM (attention output, dQ/dK/dV), the mixed pair of
+// GemmArgs::a_split == 2: hi at p, the four residual bytes (e5m2, common.h) at byte 2*plane + col of the row, where
+// `col` is the column of p inside its `plane`-wide hi block
+template <typename T>
+__device__ __forceinline__ void store_pair4_m(T* p, size_t plane, int col, f32x4 v, int lo8) {
+  if (lo8) {
+    typename Vec<T>::v4 hi;
+    const uint32_t w = split_lo8x4<T>(v, hi);
+    *(typename Vec<T>::v4*)p = hi;
+    *(uint32_t*)((char*)(p - col) + 2 * plane + col) = w;
+  } else store_pair4<T>(p, plane, v);
+}
+template <typename T>
+__device__ __forceinline__ f32x4 load_pair4_m(const T* p, size_t plane, int col, int lo8) {
+  if (!lo8) {
+    const typename Vec<T>::v4 hi = *(const typename Vec<T>::v4*)p, lo = *(const typename Vec<T>::v4*)(p + plane);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = to_f32<T>(hi[e]) + to_f32<T>(lo[e]);
+    return r;
+  }
+  const typename Vec<T>::v4 hi = *(const typename Vec<T>::v4*)p;
+  const uint32_t w = *(const uint32_t*)((const char*)(p - col) + 2 * plane + col);
+  return f32x4{join_lo8<T>(hi[0], w, 0), join_lo8<T>(hi[1], w, 1), join_lo8<T>(hi[2], w, 2), join_lo8<T>(hi[3], w, 3)};
+}
 template <typename T>
 __device__ __forceinline__ f32x4 load_pair4(const T* p, size_t lo_off) {
   const typename Vec<T>::v4 hi = *(const typename Vec<T>::v4*)p, lo = *(const typename Vec<T>::v4*)(p + lo_off);
@@ -231,7 +256,7 @@ __global__ __launch_bounds__(NW * 64) void attn32x_fwd_kernel(Attn32Args a, int 
       const float inv = 1.f / lt;
       T* orow = (T*)a.out_split + ((size_t)n * L + q[t]) * (2 * (size_t)d) + h * 64;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, d, O[t][dt] * inv);
+      for (int dt = 0; dt < 4; ++dt) store_pair4_m<T>(orow + 16 * dt + 4 * fg, d, h * 64 + 16 * dt + 4 * fg, O[t][dt] * inv, a.out_lo8);
       if (a.lse && fg == 0) a.lse[((size_t)n * a.H + h) * L + q[t]] = m[t] * SCALE + logf(lt);
     }
   }
@@ -273,7 +298,7 @@ __device__ __forceinline__ void attn32x_dq_phase(const Attn32BwdArgs& a, int nh,
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const f32x4 o = load_pair4<T>(orow + 16 * k + 4 * fg, d);
+      const f32x4 o = load_pair4_m<T>(orow + 16 * k + 4 * fg, d, h * 64 + 16 * k + 4 * fg, a.lo8);
       const f32x4 g = load_pair4<T>(grow + 16 * k + 4 * fg, d);
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc += o[e] * g[e];
@@ -320,7 +345,7 @@ __device__ __forceinline__ void attn32x_dq_phase(const Attn32BwdArgs& a, int nh,
     if (q[t] < L) {
       T* row = (T*)a.dqkv_split + ((size_t)n * L + q[t]) * ld + h * 64;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) store_pair4<T>(row + 16 * dt + 4 * fg, lo, dQ[t][dt] * SCALE);
+      for (int dt = 0; dt < 4; ++dt) store_pair4_m<T>(row + 16 * dt + 4 * fg, lo, h * 64 + 16 * dt + 4 * fg, dQ[t][dt] * SCALE, a.lo8);
     }
 }
 
@@ -404,8 +429,8 @@ __device__ __forceinline__ void attn32x_dkv_phase(const Attn32BwdArgs& a, int nh
       T* row = (T*)a.dqkv_split + ((size_t)n * L + kk[t]) * ld + h * 64;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        store_pair4<T>(row + d + 16 * dt + 4 * fg, lo, dK[t][dt] * SCALE);
-        store_pair4<T>(row + 2 * d + 16 * dt + 4 * fg, lo, dV[t][dt]);
+        store_pair4_m<T>(row + d + 16 * dt + 4 * fg, lo, d + h * 64 + 16 * dt + 4 * fg, dK[t][dt] * SCALE, a.lo8);
+        store_pair4_m<T>(row + 2 * d + 16 * dt + 4 * fg, lo, 2 * d + h * 64 + 16 * dt + 4 * fg, dV[t][dt], a.lo8);
       }
     }
 }
@@ -564,7 +589,7 @@ __global__ __launch_bounds__(SNT * 64) void attn32t_fwd_kernel(Attn32Args a) {
     const float inv = 1.f / sum;
     T* orow = (T*)a.out_split + ((size_t)n * L + q) * (2 * (size_t)d) + h * 64;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, d, O[dt] * inv);
+    for (int dt = 0; dt < 4; ++dt) store_pair4_m<T>(orow + 16 * dt + 4 * fg, d, h * 64 + 16 * dt + 4 * fg, O[dt] * inv, a.out_lo8);
     if (a.lse && fg == 0) a.lse[((size_t)n * a.H + h) * L + q] = mx * SCALE + logf(sum);
   }
 }
@@ -599,7 +624,7 @@ __global__ __launch_bounds__(SNT * 64) void attn32t_bwd_kernel(Attn32BwdArgs a) 
     const T* grow = gbase + (size_t)rc * gld;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const f32x4 o = load_pair4<T>(orow + 16 * t + 4 * fg, d), g = load_pair4<T>(grow + 16 * t + 4 * fg, d);
+      const f32x4 o = load_pair4_m<T>(orow + 16 * t + 4 * fg, d, h * 64 + 16 * t + 4 * fg, a.lo8), g = load_pair4<T>(grow + 16 * t + 4 * fg, d);
 #pragma unroll
       for (int e = 0; e < 4; ++e) dl += o[e] * g[e];
     }
@@ -636,7 +661,7 @@ __global__ __launch_bounds__(SNT * 64) void attn32t_bwd_kernel(Attn32BwdArgs a) 
     accum_all3<T>(dQ, I0h, I0l, dS, 0, kt_end, fr, fg);
     if (row < L) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) store_pair4<T>(orow + 16 * dt + 4 * fg, lo, dQ[dt] * SCALE);
+      for (int dt = 0; dt < 4; ++dt) store_pair4_m<T>(orow + 16 * dt + 4 * fg, lo, h * 64 + 16 * dt + 4 * fg, dQ[dt] * SCALE, a.lo8);
     }
   }
   __syncthreads();
@@ -673,8 +698,8 @@ __global__ __launch_bounds__(SNT * 64) void attn32t_bwd_kernel(Attn32BwdArgs a) 
     if (row < L) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        store_pair4<T>(orow + d + 16 * dt + 4 * fg, lo, dK[dt] * SCALE);
-        store_pair4<T>(orow + 2 * d + 16 * dt + 4 * fg, lo, dV[dt]);
+        store_pair4_m<T>(orow + d + 16 * dt + 4 * fg, lo, d + h * 64 + 16 * dt + 4 * fg, dK[dt] * SCALE, a.lo8);
+        store_pair4_m<T>(orow + 2 * d + 16 * dt + 4 * fg, lo, 2 * d + h * 64 + 16 * dt + 4 * fg, dV[dt], a.lo8);
       }
     }
   }

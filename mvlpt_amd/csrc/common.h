@@ -46,6 +46,59 @@ __device__ __forceinline__ void split16(float v, T& hi, T& lo) {
   lo = from_f32<T>(v - to_f32<T>(hi));
 }
 
+// Mixed split pair (GemmArgs::a_split == 2): hi = round16(v) as above, the residual travels as ONE byte,
+// lo8 = e5m2(lo * 2^LO8_EXP).  |lo| <= ulp(hi)/2, i.e. <= 2^-11 |v| (fp16) / 2^-8 |v| (bf16), so with the exponents below
+// lo * 2^LO8_EXP stays below the e5m2 maximum (57344) for every finite fp16 value (bf16: clamped), and e5m2's 30 octaves of
+// normals cover the residuals of |v| >= 2^-12: the exponent is a constant of the data type, not of the tensor.  The
+// consumer multiplies lo8 with the weight's e4m3 copy on v_mfma_scale_f32_16x16x128_f8f6f4 (the scale operand undoes 2^LO8_EXP).
+template <typename T> struct Lo8;
+template <> struct Lo8<f16> { static constexpr int EXP = 10; };
+template <> struct Lo8<bf16> { static constexpr int EXP = 7; };
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// acc += W8 (e4m3, 16 x 128) x A8 (e5m2, 128 x 16) with the two e8m0 scale bytes (byte 0 of sw / sa).  Inline asm with the
+// accumulator TIED to the destination: through the builtin hipcc gives this instruction a destination distinct from its
+// accumulator input (an early-clobber form), which doubles the live accumulators of a GEMM main loop (+64 VGPRs on a
+// 64x64 wave tile, spills on 128x64).  Hazards around it: sources come from ds_read (waitcnt is inserted for asm operands),
+// a following MFMA on the same accumulator needs no wait state; a following VALU read of acc needs 11 (8-pass XDL op) —
+// callers end a run of these with mfma_lo8_fence().
+__device__ __forceinline__ void mfma_lo8(const i32x8& w8, const i32x8& a8, f32x4& acc, int sw, int sa) {
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] blgp:1"
+               : "+v"(acc) : "v"(w8), "v"(a8), "v"(sw), "v"(sa));
+}
+__device__ __forceinline__ void mfma_lo8_fence() { asm volatile("s_nop 7\n\ts_nop 4" ::: "memory"); }
+
+// hi[0..3] (16-bit) and the four lo8 bytes (little endian: byte e belongs to v[e]) of four fp32 values
+template <typename T>
+__device__ __forceinline__ uint32_t split_lo8x4(f32x4 v, typename Vec<T>::v4& hi) {
+  float l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float x = v[e];
+    asm volatile("" : "+v"(x));
+    hi[e] = from_f32<T>(x);
+    l[e] = (x - to_f32<T>(hi[e])) * (float)(1 << Lo8<T>::EXP);
+    if constexpr (sizeof(T) == 2 && Lo8<T>::EXP != 10) l[e] = fminf(fmaxf(l[e], -57344.0f), 57344.0f);
+  }
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_bf8_f32(l[0], l[1], w, false);
+  w = __builtin_amdgcn_cvt_pk_bf8_f32(l[2], l[3], w, true);
+  return (uint32_t)w;
+}
+// value of a stored (hi, lo8) element
+template <typename T>
+__device__ __forceinline__ float join_lo8(T hi, uint32_t lo8_word, int byte) {
+  float l;
+  switch (byte) {
+    case 0: l = __builtin_amdgcn_cvt_f32_bf8((int)lo8_word, 0); break;
+    case 1: l = __builtin_amdgcn_cvt_f32_bf8((int)lo8_word, 1); break;
+    case 2: l = __builtin_amdgcn_cvt_f32_bf8((int)lo8_word, 2); break;
+    default: l = __builtin_amdgcn_cvt_f32_bf8((int)lo8_word, 3); break;
+  }
+  return to_f32<T>(hi) + l * (1.0f / (float)(1 << Lo8<T>::EXP));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

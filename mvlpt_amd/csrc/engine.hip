@@ -63,7 +63,15 @@ struct Bump {
 };
 static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-struct Linear { void* w = nullptr; void* wt = nullptr; float* b = nullptr; int out = 0, in = 0; };
+// Packed frozen weight of one nn.Linear: rows of [W16 (K x 16 bit) | W8 (K bytes, e4m3(W * 2^e8))] with a pitch of 3K/2
+// elements, in both orientations (GemmArgs::a_split == 2 reads the fp8 plane, every other GEMM only the 16-bit one).
+struct WRef { const void* p; int ld; int e8; };
+struct Linear {
+  void* w = nullptr; void* wt = nullptr; float* b = nullptr; int out = 0, in = 0;
+  int ldw = 0, ldwt = 0, e8 = 0;
+  WRef fw() const { return WRef{w, ldw, e8}; }      // forward Bt operand  [out, in]
+  WRef bw() const { return WRef{wt, ldwt, e8}; }    // dX Bt operand       [in, out]
+};
 struct LNp { float* g = nullptr; float* b = nullptr; };
 struct Block { LNp ln1, ln2; Linear qkv, o, fc, pr; };
 struct TowerW { int width = 0, layers = 0, heads = 0; std::vector<Block> blocks; };
@@ -71,6 +79,7 @@ struct TowerW { int width = 0, layers = 0, heads = 0; std::vector<Block> blocks;
 struct TowerState {
   bool valid = false, saved = false, causal = false;
   bool exact = false;                    // split-precision operands + pair-product attention (see DESIGN.md "Precision modes")
+  int xs = 0;                            // GEMM A operands: 0 single 16-bit, 1 16-bit pair, 2 mixed pair (hi + e5m2 residual byte)
   int N = 0, L = 0, d = 0, H = 0, layers = 0;
   std::vector<float*> x;                 // 2*layers+1 entries (all equal when !saved)
   std::vector<void*> qkv, attn, u;       // per layer (all equal when !saved)
@@ -90,6 +99,7 @@ struct Engine {
   MvlptArch arch{};
   int dt = DT_F16;
   int prec_mode = MVLPT_PREC_SPLIT_GRAD;
+  bool lo8 = true;      // split towers of MVLPT_PREC_SPLIT_GRAD use the mixed pair (hi + e5m2 residual byte; MVLPT_SPLIT_LO8=0: 16-bit pairs)
   std::string err;
   TowerW vis, txt;
   // vision extras
@@ -144,10 +154,11 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------------------------------------ kernel wrappers
-hipError_t gemm(Engine* E, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
+hipError_t gemm(Engine* E, int epi, const void* A, WRef Bt, int M, int N, int K, const float* bias, const void* aux,
                 const float* resid, void* out, void* out2, hipStream_t s, int dtype = -1, int a_split = 0) {
-  GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
-  g.a_split = a_split;
+  GemmArgs g{A, Bt.p, M, N, K, bias, aux, resid, out, out2};
+  g.a_split = a_split; g.ldb = Bt.ld; g.w8_exp = Bt.e8;
+  g.out_lo8 = (a_split == 2 && (epi == EPI_GELU_SPLIT || epi == EPI_GELUBWD_SPLIT)) ? 1 : 0;
   const int dt = dtype >= 0 ? dtype : E->dt;
   const double ob = (epi == EPI_RESID32) ? 8.0 : ((epi == EPI_STORE32 || epi == EPI_STORE_SPLIT) ? 4.0 : ((epi == EPI_GELUBWD || epi == EPI_GELU_SPLIT) ? 4.0 :
                     (epi == EPI_GELUBWD_SPLIT ? 6.0 : 2.0)));
@@ -158,10 +169,12 @@ hipError_t gemm(Engine* E, int epi, const void* A, const void* Bt, int M, int N,
       for (int i = 0; i < 512; ++i) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) break; E->ev_pool.push_back(ev); }
     if (E->ev_used + 2 <= E->ev_pool.size()) {
       ea = E->ev_pool[E->ev_used++]; eb = E->ev_pool[E->ev_used++];
-      // flops = ALGORITHMIC (what the reference's fp32 GEMM does: 2MNK); the split-precision mode executes twice that
+      // flops = ALGORITHMIC (what the reference's fp32 GEMM does: 2MNK); the split-precision modes execute twice that
+      // (16-bit pair) or 1.5x in 16-bit-MFMA time (mixed pair: the residual term runs on the fp8 MFMA at twice the rate)
+      const double xa = a_split == 2 ? 1.5 : (a_split ? 2.0 : 1.0);
       E->prof.push_back(ProfRec{PC_GEMM, ea, eb, 2.0 * M * N * K,
-                                2.0 * ((double)M * K * (a_split ? 2 : 1) + (double)N * K) + ob * M * N + (out2 ? 2.0 * M * N : 0),
-                                2.0 * M * N * K * (a_split ? 2 : 1)});
+                                2.0 * ((double)M * K * xa + (double)N * K * (a_split == 2 ? 1.5 : 1.0)) + ob * M * N + (out2 ? 2.0 * M * N : 0),
+                                2.0 * M * N * K * xa});
     }
   }
   return launch_gemm(dt, epi, g, s, ea, eb);
@@ -169,7 +182,7 @@ hipError_t gemm(Engine* E, int epi, const void* A, const void* Bt, int M, int N,
 hipError_t ln_fwd(Engine* E, int out_dt, const float* x, const int32_t* idx, int row_mul, const LNp& p, void* y, int rows, int d,
                   hipStream_t s, int split = 0) {
   LnFwdArgs a{x, idx, row_mul, p.g, p.b, y, rows, d};
-  a.split = (split && out_dt != DT_F32) ? 1 : 0;
+  a.split = (split && out_dt != DT_F32) ? split : 0;
   ProfScope ps(E, s, PC_LN_FWD, 8.0 * rows * d, (double)rows * d * (4.0 + (out_dt == DT_F32 ? 4.0 : 2.0)));
   return launch_ln_fwd(out_dt, a, s);
 }
@@ -199,10 +212,11 @@ size_t tower_bytes(const TowerW& W, int N, int L, bool save, bool exact) {
   }
   return b + 4096;
 }
-void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool save, bool causal, bool exact) {
+void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool save, bool causal, bool exact, int xs) {
   const size_t T = (size_t)N * L, d = W.width, H = W.heads, X = exact ? 2 : 1; const int nl = W.layers;
   st = TowerState();
   st.N = N; st.L = L; st.d = (int)d; st.H = (int)H; st.layers = nl; st.saved = save; st.causal = causal; st.exact = exact;
+  st.xs = exact ? xs : 0;
   st.x.resize(2 * nl + 1); st.qkv.resize(nl); st.attn.resize(nl); st.u.resize(nl); st.lse.resize(nl); st.skip.assign(nl, 0);
   float* x0 = bp.take<float>(T * d);
   for (int i = 0; i < 2 * nl + 1; ++i) st.x[i] = (save && i > 0) ? bp.take<float>(T * d) : x0;
@@ -225,9 +239,14 @@ void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool s
   st.valid = true;
 }
 
+// which pair format a split tower uses: the default mode carries the residual as one e5m2 byte (GemmArgs::a_split == 2);
+// MVLPT_PREC_SPLIT_ALL (PREC = "fp32": as exact as this engine gets) keeps 16-bit pairs everywhere
+int split_kind(const Engine* E) { return (E->prec_mode == MVLPT_PREC_SPLIT_ALL || !E->lo8) ? 1 : 2; }
+
 // attention core of the split-precision mode: qkv pair [T,6d] -> O as a hi|lo pair [T,2d]
 int attn32_fwd(Engine* E, TowerState& st, int l, int q_rows, hipStream_t s) {
   Attn32Args a{st.qkv[l], st.attn[l], st.saved ? st.lse[l] : nullptr, st.N, st.L, st.H, st.causal ? 1 : 0, q_rows};
+  a.out_lo8 = st.xs == 2 ? 1 : 0;
   const double rows = q_rows > 0 ? (double)q_rows : (double)st.L;
   ProfScope ps(E, s, PC_ATTN_FWD, 4.0 * rows * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0), (double)st.N * st.L * st.d * 16.0);
   HIPCHK(E, launch_attn32_fwd(E->dt, a, s));
@@ -235,6 +254,7 @@ int attn32_fwd(Engine* E, TowerState& st, int l, int q_rows, hipStream_t s) {
 }
 int attn32_bwd(Engine* E, TowerState& st, int l, hipStream_t s) {
   Attn32BwdArgs a{st.qkv[l], st.attn[l], st.dO16, st.lse[l], st.delta, st.dqkv16, st.N, st.L, st.H, st.causal ? 1 : 0};
+  a.lo8 = st.xs == 2 ? 1 : 0;
   ProfScope ps(E, s, PC_ATTN_BWD, 14.0 * st.L * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0), (double)st.N * st.L * st.d * 32.0);
   HIPCHK(E, launch_attn32_bwd(E->dt, a, s));
   return 0;
@@ -246,25 +266,25 @@ int block_fwd_x(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s
   const Block& B = W.blocks[l];
   const int T = st.N * st.L, d = st.d;
   float* xin = st.x[2 * l]; float* xmid = st.x[2 * l + 1]; float* xout = st.x[2 * l + 2];
-  HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, B.ln1, st.h16, T, d, s, 1));
-  HIPCHK(E, gemm(E, EPI_STORE_SPLIT, st.h16, B.qkv.w, T, 3 * d, d, B.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, 1));
+  HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, B.ln1, st.h16, T, d, s, st.xs));
+  HIPCHK(E, gemm(E, EPI_STORE_SPLIT, st.h16, B.qkv.fw(), T, 3 * d, d, B.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, st.xs));
   if (int rc = attn32_fwd(E, st, l, 0, s)) return rc;
-  HIPCHK(E, gemm(E, EPI_RESID32, st.attn[l], B.o.w, T, d, d, B.o.b, nullptr, xin, xmid, nullptr, s, -1, 1));
-  HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, B.ln2, st.h16, T, d, s, 1));
-  HIPCHK(E, gemm(E, EPI_GELU_SPLIT, st.h16, B.fc.w, T, 4 * d, d, B.fc.b, nullptr, nullptr, st.a16, st.saved ? st.u[l] : nullptr, s, -1, 1));
-  HIPCHK(E, gemm(E, EPI_RESID32, st.a16, B.pr.w, T, d, 4 * d, B.pr.b, nullptr, xmid, xout, nullptr, s, -1, 1));
+  HIPCHK(E, gemm(E, EPI_RESID32, st.attn[l], B.o.fw(), T, d, d, B.o.b, nullptr, xin, xmid, nullptr, s, -1, st.xs));
+  HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, B.ln2, st.h16, T, d, s, st.xs));
+  HIPCHK(E, gemm(E, EPI_GELU_SPLIT, st.h16, B.fc.fw(), T, 4 * d, d, B.fc.b, nullptr, nullptr, st.a16, st.saved ? st.u[l] : nullptr, s, -1, st.xs));
+  HIPCHK(E, gemm(E, EPI_RESID32, st.a16, B.pr.fw(), T, d, 4 * d, B.pr.b, nullptr, xmid, xout, nullptr, s, -1, st.xs));
   return 0;
 }
 int block_bwd_x(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
   const Block& B = W.blocks[l];
   const int T = st.N * st.L, d = st.d;
-  HIPCHK(E, gemm(E, EPI_GELUBWD_SPLIT, st.dx16, B.pr.wt, T, 4 * d, d, nullptr, st.u[l], nullptr, st.du16, nullptr, s, -1, 1));
-  HIPCHK(E, gemm(E, EPI_STORE32, st.du16, B.fc.wt, T, d, 4 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, 1));
-  HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l + 1], nullptr, 1, B.ln2, st.dx32, st.dx32, st.dx16, T, d, s, -1, 1));
-  HIPCHK(E, gemm(E, EPI_STORE_SPLIT, st.dx16, B.o.wt, T, d, d, nullptr, nullptr, nullptr, st.dO16, nullptr, s, -1, 1));
+  HIPCHK(E, gemm(E, EPI_GELUBWD_SPLIT, st.dx16, B.pr.bw(), T, 4 * d, d, nullptr, st.u[l], nullptr, st.du16, nullptr, s, -1, st.xs));
+  HIPCHK(E, gemm(E, EPI_STORE32, st.du16, B.fc.bw(), T, d, 4 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, st.xs));
+  HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l + 1], nullptr, 1, B.ln2, st.dx32, st.dx32, st.dx16, T, d, s, -1, st.xs));
+  HIPCHK(E, gemm(E, EPI_STORE_SPLIT, st.dx16, B.o.bw(), T, d, d, nullptr, nullptr, nullptr, st.dO16, nullptr, s, -1, st.xs));
   if (int rc = attn32_bwd(E, st, l, s)) return rc;
-  HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, B.qkv.wt, T, d, 3 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, 1));
-  HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, B.ln1, st.dx32, st.dx32, st.dx16, T, d, s, -1, 1));
+  HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, B.qkv.bw(), T, d, 3 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, st.xs));
+  HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, B.ln1, st.dx32, st.dx32, st.dx16, T, d, s, -1, st.xs));
   return 0;
 }
 
@@ -275,17 +295,17 @@ int block_fwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) 
   const int T = st.N * st.L, d = st.d;
   float* xin = st.x[2 * l]; float* xmid = st.x[2 * l + 1]; float* xout = st.x[2 * l + 2];
   HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, B.ln1, st.h16, T, d, s));
-  HIPCHK(E, gemm(E, EPI_STORE16, st.h16, B.qkv.w, T, 3 * d, d, B.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s));
+  HIPCHK(E, gemm(E, EPI_STORE16, st.h16, B.qkv.fw(), T, 3 * d, d, B.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s));
   {
     AttnArgs a{st.qkv[l], st.attn[l], st.saved ? st.lse[l] : nullptr, st.N, st.L, st.H, st.causal ? 1 : 0};
     const double fl = 4.0 * st.L * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0);
     ProfScope ps(E, s, PC_ATTN_FWD, fl, (double)T * d * 2.0 * 4.0);
     HIPCHK(E, launch_attn_fwd(E->dt, a, s));
   }
-  HIPCHK(E, gemm(E, EPI_RESID32, st.attn[l], B.o.w, T, d, d, B.o.b, nullptr, xin, xmid, nullptr, s));
+  HIPCHK(E, gemm(E, EPI_RESID32, st.attn[l], B.o.fw(), T, d, d, B.o.b, nullptr, xin, xmid, nullptr, s));
   HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, B.ln2, st.h16, T, d, s));
-  HIPCHK(E, gemm(E, EPI_GELU, st.h16, B.fc.w, T, 4 * d, d, B.fc.b, nullptr, nullptr, st.a16, st.saved ? st.u[l] : nullptr, s));
-  HIPCHK(E, gemm(E, EPI_RESID32, st.a16, B.pr.w, T, d, 4 * d, B.pr.b, nullptr, xmid, xout, nullptr, s));
+  HIPCHK(E, gemm(E, EPI_GELU, st.h16, B.fc.fw(), T, 4 * d, d, B.fc.b, nullptr, nullptr, st.a16, st.saved ? st.u[l] : nullptr, s));
+  HIPCHK(E, gemm(E, EPI_RESID32, st.a16, B.pr.fw(), T, d, 4 * d, B.pr.b, nullptr, xmid, xout, nullptr, s));
   return 0;
 }
 
@@ -294,18 +314,18 @@ int block_bwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) 
   if (st.exact) return block_bwd_x(E, W, st, l, s);
   const Block& B = W.blocks[l];
   const int T = st.N * st.L, d = st.d;
-  HIPCHK(E, gemm(E, EPI_GELUBWD, st.dx16, B.pr.wt, T, 4 * d, d, nullptr, st.u[l], nullptr, st.du16, nullptr, s));
+  HIPCHK(E, gemm(E, EPI_GELUBWD, st.dx16, B.pr.bw(), T, 4 * d, d, nullptr, st.u[l], nullptr, st.du16, nullptr, s));
   // the dX GEMMs that feed a LayerNorm backward store fp32 (one 16-bit rounding less per half layer)
-  HIPCHK(E, gemm(E, EPI_STORE32, st.du16, B.fc.wt, T, d, 4 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s));
+  HIPCHK(E, gemm(E, EPI_STORE32, st.du16, B.fc.bw(), T, d, 4 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s));
   HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l + 1], nullptr, 1, B.ln2, st.dx32, st.dx32, st.dx16, T, d, s));
-  HIPCHK(E, gemm(E, EPI_STORE16, st.dx16, B.o.wt, T, d, d, nullptr, nullptr, nullptr, st.dO16, nullptr, s));
+  HIPCHK(E, gemm(E, EPI_STORE16, st.dx16, B.o.bw(), T, d, d, nullptr, nullptr, nullptr, st.dO16, nullptr, s));
   {
     AttnBwdArgs a{st.qkv[l], st.attn[l], st.dO16, st.lse[l], st.delta, st.dqkv16, st.N, st.L, st.H, st.causal ? 1 : 0};
     const double fl = 14.0 * st.L * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0);
     ProfScope ps(E, s, PC_ATTN_BWD, fl, (double)T * d * 2.0 * 8.0);
     HIPCHK(E, launch_attn_bwd(E->dt, a, s));
   }
-  HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, B.qkv.wt, T, d, 3 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s));
+  HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, B.qkv.bw(), T, d, 3 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s));
   HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, B.ln1, st.dx32, st.dx32, st.dx16, T, d, s));
   return 0;
 }
@@ -326,14 +346,27 @@ int upload_f32(Engine* E, const float* src32, size_t n, float** dst, hipStream_t
   HIPCHK(E, hipMemcpyAsync(p, src32, n * 4, hipMemcpyDeviceToDevice, s));
   *dst = (float*)p; return 0;
 }
-int pack_linear(Engine* E, const float* w32, int out, int in, Linear* L, hipStream_t s, int ld_in = -1) {
-  const int ld = ld_in > 0 ? ld_in : in;
+int pack_linear(Engine* E, const float* w32, int out, int in, Linear* L, hipStream_t s) {
+  // rows of [16-bit plane | fp8 plane]: pitch 3K/2 elements (K = the contraction length of that orientation)
+  const int ldw = in + in / 2, ldwt = out + out / 2;
   void *w = nullptr, *wt = nullptr;
-  HIPCHK(E, hipMalloc(&w, (size_t)out * ld * 2)); E->owned.push_back(w);
-  HIPCHK(E, hipMalloc(&wt, (size_t)out * in * 2)); E->owned.push_back(wt);
-  HIPCHK(E, launch_pack_weight(E->dt, w32, w, out, in, ld, s));
-  HIPCHK(E, launch_pack_weight_t(E->dt, w32, wt, out, in, s));
-  L->w = w; L->wt = wt; L->out = out; L->in = in; return 0;
+  HIPCHK(E, hipMalloc(&w, (size_t)out * ldw * 2)); E->owned.push_back(w);
+  HIPCHK(E, hipMalloc(&wt, (size_t)in * ldwt * 2)); E->owned.push_back(wt);
+  HIPCHK(E, launch_pack_weight(E->dt, w32, w, out, in, ldw, s));
+  HIPCHK(E, launch_pack_weight_t(E->dt, w32, wt, out, in, s, ldwt));
+  // fp8 planes: W8 = e4m3(W * 2^e8), amax(|W|) * 2^e8 in [128, 256) (e4m3 tops out at 448); the exponent comes back to the
+  // host once per tensor (load time), the GEMM gets it by value
+  HIPCHK(E, E->ce_ws.reserve(256));
+  float* sc = (float*)E->ce_ws.p;
+  HIPCHK(E, launch_grad_scale(w32, (size_t)out * in, 128.0f, sc, s));
+  HIPCHK(E, launch_pack_weight8(w32, (uint8_t*)w + (size_t)in * 2, out, in, 0, in, (size_t)ldw * 2, sc, s));
+  HIPCHK(E, launch_pack_weight8(w32, (uint8_t*)wt + (size_t)out * 2, out, in, 1, out, (size_t)ldwt * 2, sc, s));
+  float sc_host = 1.0f;
+  HIPCHK(E, hipMemcpyAsync(&sc_host, sc, sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(E, hipStreamSynchronize(s));
+  int e8 = 0;
+  (void)frexpf(sc_host, &e8);      // sc = 0.5 * 2^e8' -> exponent e8' - 1
+  L->w = w; L->wt = wt; L->out = out; L->in = in; L->ldw = ldw; L->ldwt = ldwt; L->e8 = e8 - 1; return 0;
 }
 
 int load_block_tensor(Engine* E, TowerW& W, int layer, const char* tail, const float* p, const int64_t* shape, int ndim,
@@ -411,6 +444,7 @@ int mvlpt_create(const MvlptArch* a, void** handle) {
     return fail(nullptr, MVLPT_ERR_HIP, "no HIP device visible: libmvlpt_hip needs an AMD GPU (there is no CPU fallback)");
   Engine* E = new Engine();
   E->arch = *a; E->dt = a->compute_dtype;
+  if (const char* v = getenv("MVLPT_SPLIT_LO8")) E->lo8 = atoi(v) != 0;
   E->vis.width = a->vision_width; E->vis.layers = a->vision_layers; E->vis.heads = a->vision_heads;
   E->vis.blocks.resize(a->vision_layers);
   E->txt.width = a->text_width; E->txt.layers = a->text_layers; E->txt.heads = a->text_heads;
@@ -552,13 +586,13 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   E->dxc16 = bp.take_bytes((size_t)B * dv * 2 * X); E->dOc16 = bp.take_bytes((size_t)B * dv * 2 * X);
   E->uc16 = bp.take_bytes((size_t)B * dv * 4 * 2); E->duc16 = bp.take_bytes((size_t)B * dv * 4 * 2 * X);
   E->v_cls_last = false;
-  carve_tower(bp, E->vis, E->vs, B, Lv, save, false, exact);
+  carve_tower(bp, E->vis, E->vs, B, Lv, save, false, exact, split_kind(E));
   TowerState& st = E->vs;
   E->vB = B; E->v_nvpt = n_vpt; E->v_ndeep = n_deep;
 
   { ProfScope ps(E, s, PC_GLUE, 0, (double)npatch * E->Kp * 6.0);
     HIPCHK(E, launch_patchify(E->dt, image, image_dtype, patches, B, A.image_resolution, A.patch_size, E->Kp, s)); }
-  HIPCHK(E, gemm(E, EPI_STORE32, patches, E->conv_w, (int)npatch, dv, E->Kp, nullptr, nullptr, nullptr, pe, nullptr, s));
+  HIPCHK(E, gemm(E, EPI_STORE32, patches, WRef{E->conv_w, 0, 0}, (int)npatch, dv, E->Kp, nullptr, nullptr, nullptr, pe, nullptr, s));
   { ProfScope ps(E, s, PC_GLUE, 0, (double)B * Lv * dv * 8.0);
     HIPCHK(E, launch_assemble_tokens(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, vpt, n_vpt, st.x[0], B, G2, dv, s)); }
   bool cls_only_last = false;
@@ -591,9 +625,9 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
     float* xmid = save ? E->xcm32 : E->xc32;     // kept for the backward: LN2 input ...
     float* xout = save ? E->xco32 : E->xc32;     // ... and ln_post input
     E->v_cls_last = save;
-    const int xs = st.exact ? 1 : 0;      // split-precision operands (hi|lo pairs, twice the columns) + pair-product attention
+    const int xs = st.xs;                 // split-precision operands (hi|lo pairs, twice the columns) + pair-product attention
     HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dv, s, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dv, dv, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, st.h16, Bk.qkv.fw(), T, 3 * dv, dv, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
     if (xs) {
       // only the CLS rows of the attention output are produced: the backward (delta = rowsum(dO * O) over EVERY row, with
       // dO = 0 off the CLS rows) must not meet uninitialised memory there
@@ -607,10 +641,10 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
     { ProfScope ps(E, s, PC_GLUE, 0, (double)B * dv * 12.0);
       HIPCHK(E, launch_copy_rows_strided(st.attn[l], E->ac16, B, (size_t)Lv * dv * 2 * X, (size_t)dv * 2 * X, (int)(dv * 2 * X), s));
       HIPCHK(E, launch_copy_rows_strided(xin, E->xc32, B, (size_t)Lv * dv * 4, (size_t)dv * 4, dv * 4, s)); }
-    HIPCHK(E, gemm(E, EPI_RESID32, E->ac16, Bk.o.w, B, dv, dv, Bk.o.b, nullptr, E->xc32, xmid, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, EPI_RESID32, E->ac16, Bk.o.fw(), B, dv, dv, Bk.o.b, nullptr, E->xc32, xmid, nullptr, s, -1, xs));
     HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, Bk.ln2, E->hc16, B, dv, s, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_GELU_SPLIT : EPI_GELU, E->hc16, Bk.fc.w, B, 4 * dv, dv, Bk.fc.b, nullptr, nullptr, E->gc16, save ? E->uc16 : nullptr, s, -1, xs));
-    HIPCHK(E, gemm(E, EPI_RESID32, E->gc16, Bk.pr.w, B, dv, 4 * dv, Bk.pr.b, nullptr, xmid, xout, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_GELU_SPLIT : EPI_GELU, E->hc16, Bk.fc.fw(), B, 4 * dv, dv, Bk.fc.b, nullptr, nullptr, E->gc16, save ? E->uc16 : nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, EPI_RESID32, E->gc16, Bk.pr.fw(), B, dv, 4 * dv, Bk.pr.b, nullptr, xmid, xout, nullptr, s, -1, xs));
     HIPCHK(E, ln_fwd(E, DT_F32, xout, nullptr, 1, E->ln_post, E->cls32, B, dv, s));
   } else
   // ln_post on the CLS row, then @ proj   (trainers/mvlpt.py:88-91)
@@ -636,7 +670,7 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
   { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 4.0);
     HIPCHK(E, launch_zero(st.dx32, T * dv * 4, s)); }
   int l_top = st.layers - 1;
-  const int xs = st.exact ? 1 : 0;
+  const int xs = st.xs;
   if (E->v_cls_last) {
     // last block, CLS rows only (see mvlpt_image_fwd): ln_post, MLP, ln_2, out-proj on B compact rows; the attention
     // backward of a single query per head; then the full-width QKV^T GEMM and ln_1 (keys / values of every token)
@@ -644,10 +678,10 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
     const Block& Bk = E->vis.blocks[l];
     const int Ti = (int)T;
     HIPCHK(E, ln_bwd(E, E->dcls32, DT_F32, E->xco32, nullptr, 1, E->ln_post, nullptr, E->dxc32, E->dxc16, B, dv, s, -1, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_GELUBWD_SPLIT : EPI_GELUBWD, E->dxc16, Bk.pr.wt, B, 4 * dv, dv, nullptr, E->uc16, nullptr, E->duc16, nullptr, s, -1, xs));
-    HIPCHK(E, gemm(E, EPI_STORE32, E->duc16, Bk.fc.wt, B, dv, 4 * dv, nullptr, nullptr, nullptr, E->dhc32, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_GELUBWD_SPLIT : EPI_GELUBWD, E->dxc16, Bk.pr.bw(), B, 4 * dv, dv, nullptr, E->uc16, nullptr, E->duc16, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, EPI_STORE32, E->duc16, Bk.fc.bw(), B, dv, 4 * dv, nullptr, nullptr, nullptr, E->dhc32, nullptr, s, -1, xs));
     HIPCHK(E, ln_bwd(E, E->dhc32, DT_F32, E->xcm32, nullptr, 1, Bk.ln2, E->dxc32, E->dxc32, E->dxc16, B, dv, s, -1, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, E->dxc16, Bk.o.wt, B, dv, dv, nullptr, nullptr, nullptr, E->dOc16, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, E->dxc16, Bk.o.bw(), B, dv, dv, nullptr, nullptr, nullptr, E->dOc16, nullptr, s, -1, xs));
     if (xs) {
       // split-precision attention backward at full width on a dO that is zero except for the CLS rows
       { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 4.0);
@@ -659,7 +693,7 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
       HIPCHK(E, launch_attn_bwd_cls(E->dt, st.qkv[l], E->ac16, E->dOc16, st.lse[l], st.dqkv16, st.N, st.L, st.H, s)); }
     { ProfScope ps(E, s, PC_GLUE, 0, (double)B * dv * 8.0);      // residual path: d(block input) of the CLS rows
       HIPCHK(E, launch_copy_rows_strided(E->dxc32, st.dx32, B, (size_t)dv * 4, (size_t)Lv * dv * 4, dv * 4, s)); }
-    HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, Bk.qkv.wt, Ti, dv, 3 * dv, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, Bk.qkv.bw(), Ti, dv, 3 * dv, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, xs));
     HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, Bk.ln1, st.dx32, st.dx32, st.dx16, Ti, dv, s, -1, xs));
     if (l > 0 && E->v_ndeep > 0 && l <= E->v_ndeep) {
       ProfScope ps(E, s, PC_GLUE, 0, (double)B * n * dv * 10.0);
@@ -670,7 +704,7 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
   } else {
     HIPCHK(E, ln_bwd(E, E->dcls32, DT_F32, st.x[2 * st.layers], nullptr, Lv, E->ln_post, nullptr, st.dx32, nullptr, B, dv, s));
     { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dv * 6.0);
-      if (xs) HIPCHK(E, launch_cast_f32_split(E->dt, st.dx32, st.dx16, T, dv, nullptr, s));
+      if (xs) HIPCHK(E, launch_cast_f32_split(E->dt, st.dx32, st.dx16, T, dv, nullptr, s, xs == 2));
       else HIPCHK(E, launch_cast_f32_to16(E->dt, st.dx32, st.dx16, T * dv, nullptr, s)); }
   }
   for (int l = l_top; l >= 0; --l) {
@@ -723,7 +757,7 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
   E->tdxc16 = bp.take_bytes((size_t)C * dtw * 2 * X); E->tdOc16 = bp.take_bytes((size_t)C * dtw * 2 * X);
   E->tgc16 = bp.take_bytes((size_t)C * dtw * 8 * X); E->tuc16 = bp.take_bytes((size_t)C * dtw * 8); E->tduc16 = bp.take_bytes((size_t)C * dtw * 8 * X);
   E->t_eot_last = false;
-  carve_tower(bp, E->txt, E->ts, C, L, save, true, exact);
+  carve_tower(bp, E->txt, E->ts, C, L, save, true, exact, split_kind(E));
   TowerState& st = E->ts;
   E->tC = C; E->tL = L; E->t_nctx = n_ctx; E->t_per_class = ctx_per_class;
   { ProfScope ps(E, s, PC_GLUE, 0, (double)C * L * dtw * 12.0);
@@ -741,9 +775,9 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
     const int T = C * L;
     float* xin = st.x[2 * l];
     E->t_eot_last = save;
-    const int xs = st.exact ? 1 : 0;
+    const int xs = st.xs;
     HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dtw, s, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, st.h16, Bk.qkv.w, T, 3 * dtw, dtw, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, st.h16, Bk.qkv.fw(), T, 3 * dtw, dtw, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
     if (xs) {
       if (int rc = attn32_fwd(E, st, l, 0, s)) return rc;
     } else {
@@ -754,10 +788,10 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
     { ProfScope ps(E, s, PC_GLUE, 0, (double)C * dtw * 12.0);
       HIPCHK(E, launch_copy_rows(st.attn[l], E->tac16, E->eot_rows, C, (int)(dtw * 2 * X), 0, s));
       HIPCHK(E, launch_copy_rows(xin, E->txc32, E->eot_rows, C, dtw * 4, 0, s)); }
-    HIPCHK(E, gemm(E, EPI_RESID32, E->tac16, Bk.o.w, C, dtw, dtw, Bk.o.b, nullptr, E->txc32, E->txm32, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, EPI_RESID32, E->tac16, Bk.o.fw(), C, dtw, dtw, Bk.o.b, nullptr, E->txc32, E->txm32, nullptr, s, -1, xs));
     HIPCHK(E, ln_fwd(E, E->dt, E->txm32, nullptr, 1, Bk.ln2, E->thc16, C, dtw, s, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_GELU_SPLIT : EPI_GELU, E->thc16, Bk.fc.w, C, 4 * dtw, dtw, Bk.fc.b, nullptr, nullptr, E->tgc16, save ? E->tuc16 : nullptr, s, -1, xs));
-    HIPCHK(E, gemm(E, EPI_RESID32, E->tgc16, Bk.pr.w, C, dtw, 4 * dtw, Bk.pr.b, nullptr, E->txm32, E->txo32, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_GELU_SPLIT : EPI_GELU, E->thc16, Bk.fc.fw(), C, 4 * dtw, dtw, Bk.fc.b, nullptr, nullptr, E->tgc16, save ? E->tuc16 : nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, EPI_RESID32, E->tgc16, Bk.pr.fw(), C, dtw, 4 * dtw, Bk.pr.b, nullptr, E->txm32, E->txo32, nullptr, s, -1, xs));
     HIPCHK(E, ln_fwd(E, DT_F32, E->txo32, nullptr, 1, E->ln_final, E->eot32, C, dtw, s));
   }
   { ProfScope ps(E, s, PC_HEAD, 2.0 * C * e * dtw, 4.0 * ((double)C * dtw + (double)e * dtw + (double)C * e));
@@ -787,13 +821,13 @@ int mvlpt_text_bwd(void* h, const float* dfeat, float* dctx, mvlpt_stream_t stre
     const int l = st.layers - 1;
     const Block& Bk = E->txt.blocks[l];
     const int Ti = (int)T;
-    const int xs = st.exact ? 1 : 0;
+    const int xs = st.xs;
     const size_t X = xs ? 2 : 1;
     HIPCHK(E, ln_bwd(E, E->deot32, DT_F32, E->txo32, nullptr, 1, E->ln_final, nullptr, E->tdxc32, E->tdxc16, C, dtw, s, -1, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_GELUBWD_SPLIT : EPI_GELUBWD, E->tdxc16, Bk.pr.wt, C, 4 * dtw, dtw, nullptr, E->tuc16, nullptr, E->tduc16, nullptr, s, -1, xs));
-    HIPCHK(E, gemm(E, EPI_STORE32, E->tduc16, Bk.fc.wt, C, dtw, 4 * dtw, nullptr, nullptr, nullptr, E->tdhc32, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_GELUBWD_SPLIT : EPI_GELUBWD, E->tdxc16, Bk.pr.bw(), C, 4 * dtw, dtw, nullptr, E->tuc16, nullptr, E->tduc16, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, EPI_STORE32, E->tduc16, Bk.fc.bw(), C, dtw, 4 * dtw, nullptr, nullptr, nullptr, E->tdhc32, nullptr, s, -1, xs));
     HIPCHK(E, ln_bwd(E, E->tdhc32, DT_F32, E->txm32, nullptr, 1, Bk.ln2, E->tdxc32, E->tdxc32, E->tdxc16, C, dtw, s, -1, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, E->tdxc16, Bk.o.wt, C, dtw, dtw, nullptr, nullptr, nullptr, E->tdOc16, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, E->tdxc16, Bk.o.bw(), C, dtw, dtw, nullptr, nullptr, nullptr, E->tdOc16, nullptr, s, -1, xs));
     { ProfScope ps(E, s, PC_GLUE, 0, (double)T * dtw * 2.0);
       HIPCHK(E, launch_zero(st.dO16, T * dtw * 2 * X, s));      // (exact: dO is a hi|lo pair)
       HIPCHK(E, launch_copy_rows(E->tdOc16, st.dO16, E->eot_rows, C, (int)(dtw * 2 * X), 1, s));
@@ -805,7 +839,7 @@ int mvlpt_text_bwd(void* h, const float* dfeat, float* dctx, mvlpt_stream_t stre
       ProfScope ps(E, s, PC_ATTN_BWD, 7.0 * st.L * st.L * 64.0 * st.N * st.H, (double)T * dtw * 2.0 * 8.0);
       HIPCHK(E, launch_attn_bwd(E->dt, a, s));
     }
-    HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, Bk.qkv.wt, Ti, dtw, 3 * dtw, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, xs));
+    HIPCHK(E, gemm(E, EPI_STORE32, st.dqkv16, Bk.qkv.bw(), Ti, dtw, 3 * dtw, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, xs));
     HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l], nullptr, 1, Bk.ln1, st.dx32, st.dx32, st.dx16, Ti, dtw, s, -1, xs));
   }
   for (int l = st.layers - 2; l >= 0; --l)
@@ -897,6 +931,67 @@ int mvlpt_op_gemm_split(int dtype, int epi, const void* A, const void* Bt, int M
   GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
   g.a_split = 1;
   OPCHK(launch_gemm(dtype, epi, g, (hipStream_t)stream));
+  return 0;
+}
+// ---- mixed pair (GemmArgs::a_split == 2): [hi (cols x 16 bit) | residual bytes (cols, e5m2) | unused], pitch 2*cols elements
+int mvlpt_op_pack_weight_mixed(int dtype, const float* w32, int rows, int cols, int transposed, void* out, int* w8_exp,
+                               mvlpt_stream_t stream) {
+  if (!w32 || !out || !w8_exp || rows <= 0 || cols <= 0) { g_create_err = "pack_weight_mixed: null/invalid argument"; return MVLPT_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const int R = transposed ? cols : rows, K = transposed ? rows : cols, ld = K + K / 2;
+  float* sc = nullptr;
+  OPCHK(hipMalloc(&sc, 16));
+  if (transposed) OPCHK(launch_pack_weight_t(dtype, w32, out, rows, cols, s, ld));
+  else OPCHK(launch_pack_weight(dtype, w32, out, rows, cols, ld, s));
+  OPCHK(launch_grad_scale(w32, (size_t)rows * cols, 128.0f, sc, s));
+  OPCHK(launch_pack_weight8(w32, (uint8_t*)out + (size_t)K * 2, rows, cols, transposed, K, (size_t)ld * 2, sc, s));
+  float h = 1.0f;
+  OPCHK(hipMemcpyAsync(&h, sc, 4, hipMemcpyDeviceToHost, s));
+  OPCHK(hipStreamSynchronize(s));
+  (void)hipFree(sc);
+  int e = 0; (void)frexpf(h, &e);
+  *w8_exp = e - 1; (void)R;
+  return 0;
+}
+int mvlpt_op_gemm_mixed(int dtype, int epi, const void* A, const void* Bt, int ldb, int w8_exp, int M, int N, int K, const float* bias,
+                        const void* aux, const float* resid, void* out, void* out2, mvlpt_stream_t stream) {
+  GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
+  g.a_split = 2; g.ldb = ldb; g.w8_exp = w8_exp;
+  g.out_lo8 = (epi == EPI_GELU_SPLIT || epi == EPI_GELUBWD_SPLIT) ? 1 : 0;
+  OPCHK(launch_gemm(dtype, epi, g, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_cast_mixed(int dtype, const float* in, void* out, int64_t rows, int d, mvlpt_stream_t stream) {
+  OPCHK(launch_cast_f32_split(dtype, in, out, (size_t)rows, d, nullptr, (hipStream_t)stream, 1));
+  return 0;
+}
+int mvlpt_op_layernorm_fwd_mixed(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
+                                 mvlpt_stream_t stream) {
+  if (out_dtype == DT_F32) { g_create_err = "layernorm_fwd_mixed: 16-bit output only"; return MVLPT_ERR_ARG; }
+  LnFwdArgs a{x, nullptr, 1, gamma, beta, y, rows, d};
+  a.split = 2;
+  OPCHK(launch_ln_fwd(out_dtype, a, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_layernorm_bwd_mixed(int dtype, const void* dy, const float* x, const float* gamma, const float* resid, float* out32,
+                                 void* out16, int rows, int d, mvlpt_stream_t stream) {
+  LnBwdArgs a{dy, DT_F32, x, nullptr, 1, gamma, resid, out32, out16, rows, d};
+  a.split = 2;
+  OPCHK(launch_ln_bwd(dtype, a, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_attention32_fwd_mixed(int dtype, const void* qkv, void* out, float* lse, int N, int L, int H, int causal, int q_rows,
+                                   mvlpt_stream_t stream) {
+  Attn32Args a{qkv, out, lse, N, L, H, causal, q_rows};
+  a.out_lo8 = 1;
+  OPCHK(launch_attn32_fwd(dtype, a, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_attention32_bwd_mixed(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                                   void* dqkv, int N, int L, int H, int causal, mvlpt_stream_t stream) {
+  Attn32BwdArgs a{qkv, out, dout, lse, delta, dqkv, N, L, H, causal};
+  a.lo8 = 1;
+  OPCHK(launch_attn32_bwd(dtype, a, (hipStream_t)stream));
   return 0;
 }
 int mvlpt_op_layernorm_fwd_split(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,

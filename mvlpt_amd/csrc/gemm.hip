@@ -153,21 +153,26 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
           for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(v[e] * quick_gelu_grad(to_f32<T>(uv[i][it][e])));
           if (m < M) __builtin_nontemporal_store(w, (v4*)((T*)g.out + o));
         } else if constexpr (EPI == EPI_GELU_SPLIT || EPI == EPI_GELUBWD_SPLIT || EPI == EPI_STORE_SPLIT) {
-          v4 hi, lo, u16;
+          v4 hi, lo = {}, u16;
+          f32x4 rr;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float r;
-            if constexpr (EPI == EPI_GELU_SPLIT) { r = quick_gelu(v[e]); u16[e] = from_f32<T>(v[e]); }
-            else if constexpr (EPI == EPI_GELUBWD_SPLIT) r = v[e] * quick_gelu_grad(to_f32<T>(uv[i][it][e]));
-            else r = v[e];
-            T h, l;
-            split16<T>(r, h, l);
-            hi[e] = h; lo[e] = l;
+            if constexpr (EPI == EPI_GELU_SPLIT) { rr[e] = quick_gelu(v[e]); u16[e] = from_f32<T>(v[e]); }
+            else if constexpr (EPI == EPI_GELUBWD_SPLIT) rr[e] = v[e] * quick_gelu_grad(to_f32<T>(uv[i][it][e]));
+            else rr[e] = v[e];
+          }
+          uint32_t lo8 = 0;
+          const bool as_lo8 = EPI != EPI_STORE_SPLIT && g.out_lo8;      // mixed pair: the residual as one e5m2 byte (common.h)
+          if (as_lo8) lo8 = split_lo8x4<T>(rr, hi);
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { T h, l; split16<T>(rr[e], h, l); hi[e] = h; lo[e] = l; }
           }
           if (m < M) {
             T* row = (T*)g.out + (size_t)m * (2 * N) + nbase + c * 4;
             __builtin_nontemporal_store(hi, (v4*)row);
-            __builtin_nontemporal_store(lo, (v4*)(row + N));
+            if (as_lo8) __builtin_nontemporal_store(lo8, (uint32_t*)((char*)g.out + (size_t)m * (4 * N) + 2 * N + nbase + c * 4));
+            else __builtin_nontemporal_store(lo, (v4*)(row + N));
             if constexpr (EPI == EPI_GELU_SPLIT) { if (g.out2) __builtin_nontemporal_store(u16, (v4*)((T*)g.out2 + o)); }
           }
         } else {  // EPI_STORE32
@@ -198,6 +203,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = g.M, N = g.N, K = g.K;
   const int lda = g.a_split ? 2 * K : K;
+  const int ldb = g.ldb ? g.ldb : K;
   const T* __restrict__ A = (const T*)g.A;
   const T* __restrict__ Bt = (const T*)g.Bt;
 #ifdef MVLPT_GEMM_TRACE
@@ -237,12 +243,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       int br = n0 + (i * NW + wave) * 8 + srow; br = br < N ? br : N - 1;
-      bp[i] = Bt + (size_t)br * K + scol;
+      bp[i] = Bt + (size_t)br * ldb + scol;
     }
   };
   // load cursor (runs NS-1 K-stages ahead of the compute cursor, across tile boundaries)
-  // split-precision A ([M,2K] = [hi | lo], kernels.h): 2K/BK stages, the Bt K-index wraps after K/BK of them
-  const int nkb = K / BK, nk = g.a_split ? 2 * nkb : nkb;
+  // split-precision A ([M,2K] = [hi | lo], kernels.h): 2K/BK stages, the Bt K-index wraps after K/BK of them.
+  // Mixed pair (a_split == 2): K/BK 16-bit stages, then K/128 fp8 stages of the same byte size (128-byte rows = 128
+  // k-values); the fp8 planes follow the 16-bit ones in the A and Bt rows, so stage f sits at element offset f*BK of both.
+  const bool mixed = g.a_split == 2;
+  const int nkb = K / BK, nk = mixed ? nkb + nkb / 2 : (g.a_split ? 2 * nkb : nkb);
   int lround = 0, lt = tile_of(0), lkt = 0, lslot = 0;
   if (lt >= ntiles) return;
   set_ptrs(lt);
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
     char* base = smem + lslot * STAGE;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) glds16(ap[i] + lkt * BK, base + (i * NW + wave) * 1024);
-    const int bk = (lkt >= nkb ? lkt - nkb : lkt) * BK;
+    const int bk = ((lkt >= nkb && !mixed) ? lkt - nkb : lkt) * BK;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) glds16(bp[i] + bk, base + A_BYTES + (i * NW + wave) * 1024);
     lslot = lslot + 1 == NS ? 0 : lslot + 1;
@@ -270,6 +279,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   const int b_off = A_BYTES + (wn * 64 + fr) * 128;
   const int c0 = ((0 + fg) ^ (fr & 7)) * 16;        // k-step 0 chunk
   const int c1 = ((4 + fg) ^ (fr & 7)) * 16;        // k-step 1 chunk
+  // fp8 stage: the lane's 32 consecutive k-bytes (k = 32 fg .. 32 fg + 31) are source chunks 2 fg and 2 fg + 1
+  const int e0 = ((2 * fg) ^ (fr & 7)) * 16, e1 = ((2 * fg + 1) ^ (fr & 7)) * 16;
+  const int sc_w = 127 - g.w8_exp, sc_a = 127 - Lo8<T>::EXP;      // e8m0 scale bytes: undo the exponents of the two fp8 planes
 
   // prologue: fill NS-1 ring slots, wait for the first.  `n_issued` K-stages have been requested so far; a wait that
   // must guarantee stage j may leave the n_issued - (j + 1) younger stages in flight (vmcnt retires in order).
@@ -298,7 +310,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i >> 2][i & 3][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // One K-stage = [stage_pre: the leading waves' DMA] [MFMA body] [stage_post: trailing DMA, counted wait, barrier].
+    // The 16-bit stages and the fp8 stages of a mixed pair run as TWO loops with one body each: with both bodies behind a
+    // branch in one loop hipcc stops updating the accumulators in place (the MFMA destinations become fresh registers:
+    // +64 VGPRs on a 64x64 wave tile, spills on 128x64).
+    const bool dma_first = (NW == 4) || (NS == 2 && MVLPT_NS2_MODE == 0) || (wave < NW / 2);
+    constexpr bool DMA_MID = NS == 2 && MVLPT_NS2_MODE == 1 && NW != 4;
+    bool issued = false;
+    auto stage_pre = [&]() {
       // K-stage f + NS - 1 goes to the slot freed by the last barrier.  An LDS-DMA instruction costs its wave
       // ~100 issue cycles, as much per K-stage as the wave's 32 MFMAs; with two waves per SIMD (8-wave geometry)
       // the older wave issues its DMA BEFORE its MFMAs and the younger one AFTER, so on every SIMD one wave
@@ -306,11 +325,30 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
       // With a 2-deep ring the DMA issued in this stage is consumed right after the barrier that ends it, so nobody may
       // issue it at the END of the stage (its whole latency would be exposed): there the younger wave issues in the
       // MIDDLE of its MFMA groups instead (MVLPT_NS2_MODE 1; 0 = every wave first).
-      const bool dma_first = (NW == 4) || (NS == 2 && MVLPT_NS2_MODE == 0) || (wave < NW / 2);
-      constexpr bool DMA_MID = NS == 2 && MVLPT_NS2_MODE == 1 && NW != 4;
-      bool issued = false;
+      issued = false;
       MVLPT_TR(1);
       if (dma_first) { issued = issue(); MVLPT_TR(2); }
+    };
+    auto stage_post = [&]() {
+      MVLPT_TR(4);
+      if (!DMA_MID && !dma_first) { issued = issue(); MVLPT_TR(2); }
+      n_issued += issued ? 1 : 0;
+      // the NEXT stage (n_done + 1) must have landed (own loads) before the barrier; younger ones may stay in flight.
+      // vmcnt retires in order and counts stores: right after an epilogue the youngest operations are its ST_MIN
+      // global stores followed by the DMA just issued, so allowing ST_MIN + LOADS operations in flight still
+      // guarantees the older DMA has landed without making the wave wait for its own output stores (NS == 3 only).
+      wait_stage(n_issued - (n_done + 2), stores_pending && NS == 3 && issued);
+      MVLPT_TR(5);
+      stores_pending = false;
+      ++n_done;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      MVLPT_TR(7);
+      slot = slot + 1 == NS ? 0 : slot + 1;
+        };
+    const int nk16 = mixed ? nkb : nk;
+    for (int kt = 0; kt < nk16; ++kt) {
+      stage_pre();
       const char* base = smem + slot * STAGE;
       // Register-buffered fragment pipeline: the ds_reads of MFMA group s+1 (two A fragments, plus the four B fragments
       // when the k-step changes) are issued BEFORE the 8 MFMAs of group s, so hipcc's counted lgkmcnt lets the LDS
@@ -360,21 +398,38 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
         __builtin_amdgcn_sched_barrier(0);
         if (DMA_MID && sg == (MVLPT_NS2_POS) && !dma_first) { MVLPT_TR(3); issued = issue(); MVLPT_TR(2); }
       }
-      MVLPT_TR(4);
-      if (!DMA_MID && !dma_first) { issued = issue(); MVLPT_TR(2); }
-      n_issued += issued ? 1 : 0;
-      // the NEXT stage (n_done + 1) must have landed (own loads) before the barrier; younger ones may stay in flight.
-      // vmcnt retires in order and counts stores: right after an epilogue the youngest operations are its ST_MIN
-      // global stores followed by the DMA just issued, so allowing ST_MIN + LOADS operations in flight still
-      // guarantees the older DMA has landed without making the wave wait for its own output stores (NS == 3 only).
-      wait_stage(n_issued - (n_done + 2), stores_pending && NS == 3 && issued);
-      MVLPT_TR(5);
-      stores_pending = false;
-      ++n_done;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      MVLPT_TR(7);
-      slot = slot + 1 == NS ? 0 : slot + 1;
+      stage_post();
+    }
+    for (int kt = nk16; kt < nk; ++kt) {
+      stage_pre();
+      const char* base = smem + slot * STAGE;
+        // fp8 stage of the mixed pair: ONE k-step of 128 on v_mfma_scale_f32_16x16x128_f8f6f4 (32 cycles per instruction:
+        // the same matrix time per stage as the 64 16-bit MFMAs below, for twice the K).  B fragments (weights, e4m3) of the
+        // whole stage in registers, A fragments (residual bytes, e5m2) in a ring of two: the next one is read behind the
+        // first MFMA of the current one.
+        i32x8 b8[4], a8[2];
+        auto ld8 = [&](int off) -> i32x8 {
+          const i32x4 x = *(const i32x4*)(base + off + e0), y = *(const i32x4*)(base + off + e1);
+          return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b8[j] = ld8(b_off + j * 2048);
+        a8[0] = ld8(a_off);
+#pragma unroll
+        for (int i = 0; i < WMF; ++i) {
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_lo8(b8[0], a8[i & 1], acc[i >> 2][i & 3][0], sc_w, sc_a);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + 1 < WMF) a8[(i + 1) & 1] = ld8(a_off + (i + 1) * 2048);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 1; j < 4; ++j)
+            mfma_lo8(b8[j], a8[i & 1], acc[i >> 2][i & 3][j], sc_w, sc_a);
+          __builtin_amdgcn_sched_barrier(0);
+          if (DMA_MID && i == (WMF * 3 / 8 - 1) && !dma_first) { MVLPT_TR(3); issued = issue(); MVLPT_TR(2); }
+        }
+        mfma_lo8_fence();
+      stage_post();
     }
     MVLPT_TR(8);
     // the slot the load cursor will fill next has just been released by the barrier above: use it as scratch,
@@ -417,6 +472,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_phased_kernel(GemmArgs g) {
   const bool trail = wave >= NW / 2;
   const int M = g.M, N = g.N, K = g.K;
   const int lda = g.a_split ? 2 * K : K;
+  const int ldb = g.ldb ? g.ldb : K;
   const T* __restrict__ A = (const T*)g.A;
   const T* __restrict__ Bt = (const T*)g.Bt;
 
@@ -443,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_phased_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int br = n0 + (i * NW + wave) * 8 + srow;
-      bp[i] = Bt + (size_t)br * K + scol;
+      bp[i] = Bt + (size_t)br * ldb + scol;
     }
   };
   // split-precision A ([M,2K] = [hi | lo], kernels.h): 2K/BK stages, the Bt K-index wraps after K/BK of them
@@ -574,7 +630,9 @@ static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hi
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    if (getenv("MVLPT_DBG_CUS")) cus = atoi(getenv("MVLPT_DBG_CUS"));
+#ifdef MVLPT_DEBUG_CUS
+    if (getenv("MVLPT_DBG_CUS")) cus = atoi(getenv("MVLPT_DBG_CUS"));      // CU-scaling measurement, debug builds only
+#endif
   }
   const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
   const int resident = cus * wg_per_cu;
@@ -622,9 +680,10 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   static const int phased = getenv("MVLPT_GEMM_PHASED") ? atoi(getenv("MVLPT_GEMM_PHASED")) : 2;   // 0 off, 1 all, 2 long K
   // 256x256 needs >= 4 rounds of tiles, or >= 2 rounds when K is long (a ragged last round then costs less than the
   // smaller geometry's extra LDS traffic: N = 768, K = 3072: 315 -> 297 us with 2.3 rounds)
-  const int Keff = g.a_split ? 2 * g.K : g.K;
+  const int Keff = g.a_split == 2 ? g.K + g.K / 2 : (g.a_split ? 2 * g.K : g.K);
   const bool big = g.N % 256 == 0 && (t256 >= 1024 || (t256 >= 512 && Keff >= 2048));
-  if (t128 >= 384 && (phased == 1 || (phased == 2 && Keff >= 2048 && !big))) {
+  // (the phased kernel has no fp8 stages: mixed pairs take the plain 256x128 geometry)
+  if (g.a_split != 2 && t128 >= 384 && (phased == 1 || (phased == 2 && Keff >= 2048 && !big))) {
     *tile_m = 256; *tile_n = 128;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_phased<T, EPI>(g, s, ea, eb);
   }
@@ -638,11 +697,11 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   }
   // small problems (text tower: M = C*L ~ 7.7k rows) put at most one workgroup on a CU, so nothing hides the
   // LDS-DMA latency of a 2-deep ring: use a 4-deep ring (128 KiB, three K-stages in flight) instead
-  static const int deep = getenv("MVLPT_GEMM_DEEP") ? atoi(getenv("MVLPT_GEMM_DEEP")) : 1;   // round 1 (single operands): text tower alone -7 %, overlapped step +1.4 %
+  static const int deep = getenv("MVLPT_GEMM_DEEP") ? atoi(getenv("MVLPT_GEMM_DEEP")) : 1;   // split operands only.  round 1 (single operands): text tower alone -7 %, overlapped step +1.4 %
   // (its 128 KiB workgroups cannot share a CU with the image-tower kernels they overlap with) -> off.  Round 2 (split operands
   // double every K of the text tower): tower alone 5.57 -> 5.10 ms, overlapped step 15.22 -> 15.00 ms -> on.
   const long t_small = (long)((g.M + 127) / 128) * (g.N / 128);
-  if (deep && t_small <= num_cus()) {
+  if (deep && g.a_split && t_small <= num_cus()) {
     *tile_m = 128; *tile_n = 128;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 128, 128, 4, 4>(g, 1, s, ea, eb);
   }
@@ -698,6 +757,8 @@ static hipError_t launch_epi(const GemmArgs& g, int epi, hipStream_t s, hipEvent
 // K must be a multiple of 64 and N of 128 (every CLIP width is; conv K is zero-padded); M is arbitrary.
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N % 128) != 0) return hipErrorInvalidValue;
+  if (g.a_split == 2 && ((g.K % 128) != 0 || g.ldb < g.K + g.K / 2)) return hipErrorInvalidValue;
+  if (g.ldb && (g.ldb < g.K || (g.ldb % 8) != 0)) return hipErrorInvalidValue;
   if (epi == EPI_RESID32 && !g.resid) return hipErrorInvalidValue;
   if ((epi == EPI_GELUBWD || epi == EPI_GELUBWD_SPLIT) && !g.aux) return hipErrorInvalidValue;
   if (dtype == DT_F16) return launch_epi<f16>(g, epi, s, ea, eb);

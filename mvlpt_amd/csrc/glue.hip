@@ -33,27 +33,33 @@ hipError_t launch_cast_f32_to16(int dtype, const float* in, void* out, size_t n,
 
 // fp32 [rows, d] -> 16-bit pair [rows, 2d] = [hi | lo]  (split-precision A operand, GemmArgs::a_split)
 template <typename T>
-__global__ void cast_split_kernel(const float* __restrict__ in, T* __restrict__ out, size_t rows, int d4, const float* scale_dev) {
+__global__ void cast_split_kernel(const float* __restrict__ in, T* __restrict__ out, size_t rows, int d4, const float* scale_dev, int lo8) {
   const float sc = scale_dev ? scale_dev[0] : 1.0f;
   const size_t n4 = rows * d4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     const size_t r = i / d4; const int c = (int)(i - r * d4) * 4;
     const f32x4 v = *(const f32x4*)(in + i * 4) * sc;
     typename Vec<T>::v4 hi, lo;
+    T* row = out + r * (size_t)(8 * d4);
+    if (lo8) {      // mixed pair: [hi | lo8 bytes | unused]
+      const uint32_t w = split_lo8x4<T>(v, hi);
+      *(typename Vec<T>::v4*)(row + c) = hi;
+      *(uint32_t*)((char*)row + 8 * d4 + c) = w;
+      continue;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) { T h, l; split16<T>(v[e], h, l); hi[e] = h; lo[e] = l; }
-    T* row = out + r * (size_t)(8 * d4);
     *(typename Vec<T>::v4*)(row + c) = hi;
     *(typename Vec<T>::v4*)(row + 4 * d4 + c) = lo;
   }
 }
-hipError_t launch_cast_f32_split(int dtype, const float* in, void* out, size_t rows, int d, const float* scale_dev, hipStream_t s) {
+hipError_t launch_cast_f32_split(int dtype, const float* in, void* out, size_t rows, int d, const float* scale_dev, hipStream_t s, int lo8) {
   if (rows == 0) return hipSuccess;
   if (d % 4) return hipErrorInvalidValue;
   const size_t n4 = rows * (d / 4);
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  if (dtype == DT_F16) hipLaunchKernelGGL(cast_split_kernel<f16>, dim3(grid), dim3(256), 0, s, in, (f16*)out, rows, d / 4, scale_dev);
-  else if (dtype == DT_BF16) hipLaunchKernelGGL(cast_split_kernel<bf16>, dim3(grid), dim3(256), 0, s, in, (bf16*)out, rows, d / 4, scale_dev);
+  if (dtype == DT_F16) hipLaunchKernelGGL(cast_split_kernel<f16>, dim3(grid), dim3(256), 0, s, in, (f16*)out, rows, d / 4, scale_dev, lo8);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(cast_split_kernel<bf16>, dim3(grid), dim3(256), 0, s, in, (bf16*)out, rows, d / 4, scale_dev, lo8);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -92,7 +98,7 @@ hipError_t launch_pack_weight(int dtype, const float* w, void* out, int rows, in
 
 // tiled transpose through LDS: out[c][r] = w[r][c]
 template <typename T>
-__global__ void pack_weight_t_kernel(const float* __restrict__ w, T* __restrict__ out, int rows, int cols) {
+__global__ void pack_weight_t_kernel(const float* __restrict__ w, T* __restrict__ out, int rows, int cols, int ld_out) {
   __shared__ float tile[32][33];
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
@@ -103,15 +109,47 @@ __global__ void pack_weight_t_kernel(const float* __restrict__ w, T* __restrict_
   __syncthreads();
   for (int k = ty; k < 32; k += 8) {
     const int c = c0 + k, r = r0 + tx;
-    if (c < cols && r < rows) out[(size_t)c * rows + r] = (T)tile[tx][k];
+    if (c < cols && r < rows) out[(size_t)c * ld_out + r] = (T)tile[tx][k];
   }
 }
-hipError_t launch_pack_weight_t(int dtype, const float* w, void* out, int rows, int cols, hipStream_t s) {
+hipError_t launch_pack_weight_t(int dtype, const float* w, void* out, int rows, int cols, hipStream_t s, int ld_out) {
   dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
-  if (dtype == DT_F32) hipLaunchKernelGGL(pack_weight_t_kernel<float>, grid, block, 0, s, w, (float*)out, rows, cols);
-  else if (dtype == DT_F16) hipLaunchKernelGGL(pack_weight_t_kernel<f16>, grid, block, 0, s, w, (f16*)out, rows, cols);
-  else if (dtype == DT_BF16) hipLaunchKernelGGL(pack_weight_t_kernel<bf16>, grid, block, 0, s, w, (bf16*)out, rows, cols);
+  if (ld_out <= 0) ld_out = rows;
+  if (dtype == DT_F32) hipLaunchKernelGGL(pack_weight_t_kernel<float>, grid, block, 0, s, w, (float*)out, rows, cols, ld_out);
+  else if (dtype == DT_F16) hipLaunchKernelGGL(pack_weight_t_kernel<f16>, grid, block, 0, s, w, (f16*)out, rows, cols, ld_out);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(pack_weight_t_kernel<bf16>, grid, block, 0, s, w, (bf16*)out, rows, cols, ld_out);
   else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// fp8 plane of a packed weight (GemmArgs::a_split == 2): byte (ro, co) of the plane = e4m3(W * scale), W = w[ro][co]
+// (transposed: w[co][ro]); columns co >= the source extent are zero.  Load time only.
+__global__ void pack_weight8_kernel(const float* __restrict__ w, uint8_t* __restrict__ out8, int rows, int cols, int transposed,
+                                    int cols_out, size_t pitch_bytes, const float* scale_dev) {
+  const int rows_out = transposed ? cols : rows, cols_src = transposed ? rows : cols;
+  const float sc = scale_dev[0];
+  const size_t n4 = (size_t)rows_out * (cols_out / 4);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const int ro = (int)(i / (cols_out / 4)), co = (int)(i % (cols_out / 4)) * 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = co + e;
+      const float x = c < cols_src ? (transposed ? w[(size_t)c * cols + ro] : w[(size_t)ro * cols + c]) : 0.f;
+      v[e] = fminf(fmaxf(x * sc, -448.0f), 448.0f);
+    }
+    int word = 0;
+    word = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], word, false);
+    word = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], word, true);
+    *(uint32_t*)(out8 + (size_t)ro * pitch_bytes + co) = (uint32_t)word;
+  }
+}
+hipError_t launch_pack_weight8(const float* w, uint8_t* out8, int rows, int cols, int transposed, int cols_out, size_t pitch_bytes,
+                               const float* scale_dev, hipStream_t s) {
+  if (rows <= 0 || cols <= 0 || (cols_out % 4) || (pitch_bytes % 4)) return hipErrorInvalidValue;
+  const size_t n4 = (size_t)(transposed ? cols : rows) * (cols_out / 4);
+  const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_weight8_kernel, dim3(grid), dim3(256), 0, s, w, out8, rows, cols, transposed, cols_out, pitch_bytes, scale_dev);
   return hipGetLastError();
 }
 

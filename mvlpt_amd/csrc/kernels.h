@@ -31,7 +31,16 @@ struct GemmArgs {
   // product is A_hi*Bt^T + A_lo*Bt^T in the same fp32 accumulators: the K loop runs over 2K with the Bt K-index wrapping.
   // The frozen weights are exactly representable in 16 bits (they are stored so, clip/model.py:371-392), so the product
   // then carries the activations at ~fp32 precision.  Costs twice the MFMA work.
+  // a_split == 2 (mixed pair): A is [M, 2K] 16-bit slots per row (same pitch) holding [A_hi (K x 16 bit) | A_lo8 (K bytes) | unused],
+  // A_lo8 = e5m2(A_lo * 2^Lo8<T>::EXP) (common.h), and Bt rows hold [W16 (K x 16 bit) | W8 (K bytes)] with pitch ldb >= 3K/2
+  // elements, W8 = e4m3(W * 2^w8_exp): the product is A_hi*W16^T on v_mfma_f32_16x16x32 plus A_lo8*W8^T on
+  // v_mfma_scale_f32_16x16x128_f8f6f4 (twice the rate, the e8m0 scale operands undo the two exponents) in the same
+  // accumulators: 1.5x the matrix time of a single-operand GEMM instead of 2x, the lo term carried at ~2^-16 of the value.
+  // K % 128 == 0.
   int a_split = 0;
+  int ldb = 0;         // Bt row pitch in 16-bit elements (0: K)
+  int w8_exp = 0;      // a_split == 2: exponent of the weight's fp8 plane
+  int out_lo8 = 0;     // EPI_GELU_SPLIT / EPI_GELUBWD_SPLIT: store the pair as [hi | lo8] (mixed pair) instead of [hi | lo]
 #ifdef MVLPT_GEMM_TRACE
   long long* trace = nullptr;   // debug builds only: per-wave (point id << 56 | s_memtime) records of workgroup 0
 #endif
@@ -52,7 +61,8 @@ struct LnFwdArgs {
   const float* gamma; const float* beta;
   void* y;          // [rows,d] contiguous, 16-bit (out_dtype = compute dtype) or fp32 (out_dtype = DT_F32)
   int rows, d;
-  int split = 0;    // 16-bit outputs only: y is [rows, 2d] = [hi | lo] (split-precision A operand, see GemmArgs::a_split)
+  int split = 0;    // 16-bit outputs only: y is [rows, 2d] = [hi | lo] (split-precision A operand, see GemmArgs::a_split);
+                    // 2: same pitch, [hi | lo8 bytes | unused] (mixed pair)
 };
 hipError_t launch_ln_fwd(int out_dtype, const LnFwdArgs& a, hipStream_t s);
 
@@ -65,7 +75,7 @@ struct LnBwdArgs {
   float* out32;          // fp32, same row mapping as x (may alias resid)
   void* out16;           // optional 16-bit copy, same row mapping
   int rows, d;
-  int split = 0;         // out16 is [*, 2d] = [hi | lo]
+  int split = 0;         // out16 is [*, 2d] = [hi | lo]; 2: [hi | lo8 bytes | unused] (mixed pair)
 };
 hipError_t launch_ln_bwd(int dtype, const LnBwdArgs& a, hipStream_t s);
 
@@ -102,12 +112,14 @@ struct Attn32Args {
   float* lse;            // [N*H*L] or null
   int N, L, H; int causal;
   int q_rows = 0;        // > 0: only queries 0..q_rows-1 of every sequence are computed
+  int out_lo8 = 0;       // out_split rows are [hi(d) | lo8 (d bytes) | unused] (mixed pair: the out-projection's A operand)
 };
 hipError_t launch_attn32_fwd(int dtype, const Attn32Args& a, hipStream_t s);
 struct Attn32BwdArgs {
   const void* qkv_split; const void* out_split; const void* dout_split /*[N*L, 2d]*/; const float* lse;
   float* delta /*[N*H*L] scratch*/; void* dqkv_split /*[N*L, 6d] 16-bit: [hi(3d) | lo(3d)]*/;
   int N, L, H; int causal;
+  int lo8 = 0;           // out_split rows are [hi | lo8] (read for delta) and dqkv_split rows are written as [hi(3d) | lo8 (3d bytes) | unused]
 };
 hipError_t launch_attn32_bwd(int dtype, const Attn32BwdArgs& a, hipStream_t s);
 
@@ -128,12 +140,17 @@ hipError_t launch_preprocess(const uint8_t* src, const PpDesc* descs_dev, int B,
 // ---------------------------------------------------------------- glue
 hipError_t launch_cast_f32_to16(int dtype, const float* in, void* out, size_t n, const float* scale_dev, hipStream_t s);
 // fp32 [rows,d] (* scale_dev[0]) -> 16-bit pair [rows, 2d] = [hi | lo]
-hipError_t launch_cast_f32_split(int dtype, const float* in, void* out, size_t rows, int d, const float* scale_dev, hipStream_t s);
+// (lo8 = 1: [hi | lo8 bytes | unused], the mixed pair)
+hipError_t launch_cast_f32_split(int dtype, const float* in, void* out, size_t rows, int d, const float* scale_dev, hipStream_t s, int lo8 = 0);
 hipError_t launch_cast_any_to_f32(int in_dtype, const void* in, float* out, size_t n, hipStream_t s);
 // W [rows, cols] (fp32) -> out16 [rows, ld_out] zero padded (cols <= ld_out)
 hipError_t launch_pack_weight(int dtype, const float* w, void* out, int rows, int cols, int ld_out, hipStream_t s);
+// fp8 plane of a packed weight: out8[r, c] = e4m3(W[r, c] * scale_dev[0]) (transposed = 1: out8[c, r]), zero padded to `cols_out`
+// bytes per row; `out8` points at the plane inside the 16-bit rows, pitch_bytes apart
+hipError_t launch_pack_weight8(const float* w, uint8_t* out8, int rows, int cols, int transposed, int cols_out, size_t pitch_bytes,
+                               const float* scale_dev, hipStream_t s);
 // W [rows, cols] (fp32) -> out16 [cols, rows] (transposed)
-hipError_t launch_pack_weight_t(int dtype, const float* w, void* out, int rows, int cols, hipStream_t s);
+hipError_t launch_pack_weight_t(int dtype, const float* w, void* out, int rows, int cols, hipStream_t s, int ld_out = 0);
 // image [B,3,R,R] (fp32 / f16 / bf16) -> patches16 [B*g*g, Kp], column order (c,ky,kx), zero padded to Kp
 hipError_t launch_patchify(int dtype, const void* image, int image_dtype, void* out, int B, int R, int P, int Kp, hipStream_t s);
 // tokens: row0 = LN(cls + pos0); rows 1..n = vpt; rest = LN(patch + pos)   (trainers/mvlpt.py:56-62)

@@ -29,6 +29,22 @@ __device__ __forceinline__ void store4_split(TO* p, int lo_off, f32x4 v) {
   *(typename Vec<TO>::v4*)(p + lo_off) = lo;
 }
 template <> __device__ __forceinline__ void store4_split<float>(float* p, int, f32x4 v) { *(f32x4*)p = v; }
+// mixed pair (GemmArgs::a_split == 2): hi at row + c, the four residual bytes at byte 2d + c of the same row
+template <typename TO>
+__device__ __forceinline__ void store4_lo8(TO* row, int d, int c, f32x4 v) {
+  typename Vec<TO>::v4 hi;
+  const uint32_t lo8 = split_lo8x4<TO>(v, hi);
+  *(typename Vec<TO>::v4*)(row + c) = hi;
+  *(uint32_t*)((char*)row + 2 * d + c) = lo8;
+}
+template <> __device__ __forceinline__ void store4_lo8<float>(float* row, int, int c, f32x4 v) { *(f32x4*)(row + c) = v; }
+// split: 0 plain, 1 [hi | lo] pair, 2 mixed pair
+template <typename TO>
+__device__ __forceinline__ void store4_mode(TO* row, int d, int c, f32x4 v, int split) {
+  if (split == 2) store4_lo8<TO>(row, d, c, v);
+  else if (split) store4_split<TO>(row + c, d, v);
+  else store4<TO>(row + c, v);
+}
 template <typename TI>
 __device__ __forceinline__ f32x4 load4(const TI* p);
 template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *(const f32x4*)p; }
@@ -78,7 +94,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-    if (a.split) store4_split<TO>(y + c, a.d, o); else store4<TO>(y + c, o);
+    store4_mode<TO>(y, a.d, c, o, a.split);
   }
 }
 
@@ -124,7 +140,7 @@ __global__ __launch_bounds__(256) void ln_fwd_stream_kernel(LnFwdArgs a) {
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (cur[i][e] - mean) * rstd * g[i][e] + b[i][e];
-      if (a.split) store4_split<TO>(y + (i * 64 + lane) * 4, a.d, o); else store4<TO>(y + (i * 64 + lane) * 4, o);
+      store4_mode<TO>(y, a.d, (i * 64 + lane) * 4, o, a.split);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
@@ -185,10 +201,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     for (int e = 0; e < 4; ++e) o[e] = rstd * (gg[i][e] - s1 - v[i][e] * s2);
     if (a.resid) o += *(const f32x4*)(a.resid + in_row * a.d + c);
     *(f32x4*)(a.out32 + in_row * a.d + c) = o;
-    if (a.out16) {
-      if (a.split) store4_split<T>((T*)a.out16 + in_row * a.d * 2 + c, a.d, o);
-      else store4<T>((T*)a.out16 + in_row * a.d + c, o);
-    }
+    if (a.out16) store4_mode<T>((T*)a.out16 + in_row * a.d * (a.split ? 2 : 1), a.d, c, o, a.split);
   }
 }
 
@@ -257,10 +270,7 @@ __global__ __launch_bounds__(256) void ln_bwd_stream_kernel(LnBwdArgs a) {
       for (int e = 0; e < 4; ++e) o[e] = rstd * (dc[i][e] - s1 - xc[i][e] * s2);
       if (a.resid) o += rc[i];
       __builtin_nontemporal_store(o, (f32x4*)(a.out32 + in_row * a.d + c));
-      if (a.out16) {
-        if (a.split) store4_split<T>((T*)a.out16 + in_row * a.d * 2 + c, a.d, o);
-        else store4<T>((T*)a.out16 + in_row * a.d + c, o);
-      }
+      if (a.out16) store4_mode<T>((T*)a.out16 + in_row * a.d * (a.split ? 2 : 1), a.d, c, o, a.split);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) { xc[i] = xn[i]; dc[i] = dn[i]; rc[i] = rn[i]; }

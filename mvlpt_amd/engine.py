@@ -304,6 +304,87 @@ def op_gemm_split(A2, Bt, epi=_lib.EPI_STORE32, bias=None, aux=None, resid=None,
     return (out, o2) if out2 else out
 
 
+# ---- mixed pair: [hi (d x 16 bit) | residual bytes (d, e5m2 of (x - hi) * 2^LO8_EXP) | unused], pitch 2d 16-bit elements
+LO8_EXP = {torch.float16: 10, torch.bfloat16: 7}
+
+
+def join_mixed(p: torch.Tensor) -> torch.Tensor:
+    """Value of a mixed-pair tensor [rows, 2d] (host-side decoder for tests)."""
+    d = p.shape[1] // 2
+    lo8 = p[:, d:d + d // 2].contiguous().view(torch.uint8).view(torch.float8_e5m2).float()
+    return p[:, :d].float() + lo8 * 2.0 ** -LO8_EXP[p.dtype]
+
+
+def op_cast_mixed(x32: torch.Tensor, dtype) -> torch.Tensor:
+    rows, d = x32.shape
+    out = torch.zeros(rows, 2 * d, device=x32.device, dtype=dtype)
+    _lib.check(lib.mvlpt_op_cast_mixed(_TORCH2DT[dtype], _ptr(x32.contiguous()), _ptr(out), rows, d, _stream()), None, "op_cast_mixed")
+    return out
+
+
+def op_pack_weight_mixed(w32: torch.Tensor, dtype, transposed=False):
+    """nn.Linear weight [out, in] fp32 -> (packed [R, 3K/2] 16-bit elements = [W16 | e4m3(W * 2^e8) bytes], e8)."""
+    rows, cols = w32.shape
+    R, K = (cols, rows) if transposed else (rows, cols)
+    out = torch.zeros(R, K + K // 2, device=w32.device, dtype=dtype)
+    e8 = C.c_int(0)
+    _lib.check(lib.mvlpt_op_pack_weight_mixed(_TORCH2DT[dtype], _ptr(w32.contiguous()), rows, cols, int(transposed), _ptr(out),
+                                              C.byref(e8), _stream()), None, "op_pack_weight_mixed")
+    return out, e8.value
+
+
+def op_gemm_mixed(A2, Wp, e8, epi=_lib.EPI_STORE32, bias=None, aux=None, resid=None, out2=False):
+    """A2: mixed pair [M, 2K]; Wp: packed weight [N, 3K/2] from op_pack_weight_mixed."""
+    dt = _TORCH2DT[A2.dtype]
+    M, K = A2.shape[0], A2.shape[1] // 2
+    N = Wp.shape[0]
+    if epi in (_lib.EPI_RESID32, _lib.EPI_STORE32):
+        out = torch.empty(M, N, device=A2.device, dtype=torch.float32)
+    else:
+        out = torch.zeros(M, 2 * N, device=A2.device, dtype=A2.dtype)
+    o2 = torch.empty(M, N, device=A2.device, dtype=A2.dtype) if out2 else None
+    _lib.check(lib.mvlpt_op_gemm_mixed(dt, epi, _ptr(A2.contiguous()), _ptr(Wp), Wp.shape[1], e8, M, N, K, _ptr(bias), _ptr(aux),
+                                       _ptr(resid), _ptr(out), _ptr(o2), _stream()), None, "op_gemm_mixed")
+    return (out, o2) if out2 else out
+
+
+def op_layernorm_fwd_mixed(x, gamma, beta, out_dtype):
+    rows, d = x.shape
+    y = torch.zeros(rows, 2 * d, device=x.device, dtype=out_dtype)
+    _lib.check(lib.mvlpt_op_layernorm_fwd_mixed(_TORCH2DT[out_dtype], _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), rows, d, _stream()),
+               None, "op_layernorm_fwd_mixed")
+    return y
+
+
+def op_layernorm_bwd_mixed(dy32, x, gamma, dtype, resid=None):
+    rows, d = x.shape
+    out32 = torch.empty(rows, d, device=x.device, dtype=torch.float32)
+    out16 = torch.zeros(rows, 2 * d, device=x.device, dtype=dtype)
+    _lib.check(lib.mvlpt_op_layernorm_bwd_mixed(_TORCH2DT[dtype], _ptr(dy32), _ptr(x), _ptr(gamma), _ptr(resid), _ptr(out32),
+                                                _ptr(out16), rows, d, _stream()), None, "op_layernorm_bwd_mixed")
+    return out32, out16
+
+
+def op_attention32_fwd_mixed(qkv_pair, N, L, H, causal, q_rows=0):
+    """qkv: 16-bit pair [N*L, 6d] -> (O as a mixed pair [N*L, 2d], lse)."""
+    dtype = qkv_pair.dtype
+    out = torch.zeros(N * L, 2 * H * 64, device=qkv_pair.device, dtype=dtype)
+    lse = torch.zeros(N * H * L, device=qkv_pair.device, dtype=torch.float32)
+    _lib.check(lib.mvlpt_op_attention32_fwd_mixed(_TORCH2DT[dtype], _ptr(qkv_pair), _ptr(out), _ptr(lse), N, L, H, int(causal), q_rows,
+                                                  _stream()), None, "op_attention32_fwd_mixed")
+    return out, lse
+
+
+def op_attention32_bwd_mixed(qkv_pair, out_mixed, dout_pair, lse, N, L, H, causal):
+    """-> dqkv as a mixed pair [N*L, 6d] (hi plane 3d wide)."""
+    dtype = out_mixed.dtype
+    dqkv = torch.zeros(N * L, 6 * H * 64, device=qkv_pair.device, dtype=dtype)
+    delta = torch.empty(N * H * L, device=qkv_pair.device, dtype=torch.float32)
+    _lib.check(lib.mvlpt_op_attention32_bwd_mixed(_TORCH2DT[dtype], _ptr(qkv_pair), _ptr(out_mixed), _ptr(dout_pair), _ptr(lse),
+                                                  _ptr(delta), _ptr(dqkv), N, L, H, int(causal), _stream()), None, "op_attention32_bwd_mixed")
+    return dqkv
+
+
 def op_layernorm_fwd_split(x, gamma, beta, out_dtype):
     rows, d = x.shape
     y = torch.empty(rows, 2 * d, device=x.device, dtype=out_dtype)

@@ -16,22 +16,47 @@ from mvlpt_amd.weights import ARCHS, make_state_dict   # noqa: E402
 SITES = ["h1", "qkv", "p", "o", "h2", "a", "u", "dx_pr", "du", "dx_o", "dO", "pb", "dS", "dqkv"]
 
 
-def make_round(enabled, split):
+LO_EXP = 10          # lo8 = e5m2(lo * 2^LO_EXP): |lo| <= 2^-11 |x| < 2^5 for every finite fp16 x, never saturates
+
+
+def q_e5m2(t, exp):
+    s = 2.0 ** exp
+    return (t * s).clamp(-57344.0, 57344.0).to(torch.float8_e5m2).float() / s
+
+
+def q_e4m3(t, exp=None):
+    if exp is None:       # per-tensor power of two that puts max|t| just below 448
+        exp = math.floor(math.log2(448.0 / float(t.abs().max())))
+    s = 2.0 ** exp
+    return (t * s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() / s
+
+
+def make_round(enabled, split, mix=(), lo_fmt="e5m2"):
+    """r(t, site): plain rounding of a site; r.mm(t, site, Wt): the GEMM  round(t) @ Wt  of a GEMM-A site, where a site in
+    `mix` runs the mixed recipe  hi @ Wt + lo8 @ W8t  (lo in fp8 with a fixed exponent, the weight's fp8 copy per tensor)."""
     def r(t, site):
         if site not in enabled:
             return t
         hi = t.half().float()
-        if site in split:
+        if site in split or site in mix:
             return hi + (t - hi).half().float()
         return hi
+
+    def mm(t, site, wt):
+        if site in enabled and site in mix:
+            hi = t.half().float()
+            lo = t - hi
+            lo8 = q_e5m2(lo, LO_EXP) if lo_fmt == "e5m2" else q_e4m3(lo, LO_EXP + 2)
+            return hi @ wt + lo8 @ q_e4m3(wt)
+        return r(t, site) @ wt
+    r.mm = mm
     return r
 
 
 def block_fwd(x, sd, pre, heads, r):
     d = x.shape[-1]
     h1, ln1 = O.layernorm_fwd(x, sd[pre + "ln_1.weight"], sd[pre + "ln_1.bias"])
-    h1 = r(h1, "h1")
-    qkv = r(h1 @ sd[pre + "attn.in_proj_weight"].t() + sd[pre + "attn.in_proj_bias"], "qkv")
+    qkv = r(r.mm(h1, "h1", sd[pre + "attn.in_proj_weight"].t()) + sd[pre + "attn.in_proj_bias"], "qkv")
     q, k, v = (O._split_heads(t, heads) for t in qkv.split(d, dim=-1))
     L = q.shape[-2]
     s = torch.matmul(q, k.transpose(-1, -2)) / 8.0 + torch.full((L, L), float("-inf")).triu_(1)
@@ -40,23 +65,21 @@ def block_fwd(x, sd, pre, heads, r):
     den = e.sum(-1, keepdim=True)
     lse = m + den.log()
     p = e / den
-    o = r(torch.matmul(r(p, "p"), v), "o")
-    xm = x + O._merge_heads(o) @ sd[pre + "attn.out_proj.weight"].t() + sd[pre + "attn.out_proj.bias"]
+    o_raw = torch.matmul(r(p, "p"), v)
+    o = r(o_raw, "o")
+    xm = x + r.mm(O._merge_heads(o_raw), "o", sd[pre + "attn.out_proj.weight"].t()) + sd[pre + "attn.out_proj.bias"]
     h2, ln2 = O.layernorm_fwd(xm, sd[pre + "ln_2.weight"], sd[pre + "ln_2.bias"])
-    h2 = r(h2, "h2")
-    u = h2 @ sd[pre + "mlp.c_fc.weight"].t() + sd[pre + "mlp.c_fc.bias"]
-    a = r(O.quick_gelu(u), "a")
-    xo = xm + a @ sd[pre + "mlp.c_proj.weight"].t() + sd[pre + "mlp.c_proj.bias"]
+    u = r.mm(h2, "h2", sd[pre + "mlp.c_fc.weight"].t()) + sd[pre + "mlp.c_fc.bias"]
+    xo = xm + r.mm(O.quick_gelu(u), "a", sd[pre + "mlp.c_proj.weight"].t()) + sd[pre + "mlp.c_proj.bias"]
     return xo, (ln1, q, k, v, lse, o, ln2, r(u, "u"))
 
 
 def block_bwd(dx, saved, sd, pre, r):
     ln1, q, k, v, lse, o, ln2, u = saved
-    da = r(dx, "dx_pr") @ sd[pre + "mlp.c_proj.weight"]
-    du = r(da * O.quick_gelu_grad(u), "du")
-    dh2 = du @ sd[pre + "mlp.c_fc.weight"]
+    da = r.mm(dx, "dx_pr", sd[pre + "mlp.c_proj.weight"])
+    dh2 = r.mm(da * O.quick_gelu_grad(u), "du", sd[pre + "mlp.c_fc.weight"])
     dxm = dx + O.layernorm_bwd(dh2, ln2[0], ln2[1], sd[pre + "ln_2.weight"])
-    do = O._split_heads(r(r(dxm, "dx_o") @ sd[pre + "attn.out_proj.weight"], "dO"), q.shape[1])
+    do = O._split_heads(r(r.mm(dxm, "dx_o", sd[pre + "attn.out_proj.weight"]), "dO"), q.shape[1])
     L = q.shape[-2]
     s = torch.matmul(q, k.transpose(-1, -2)) / 8.0 + torch.full((L, L), float("-inf")).triu_(1)
     p = torch.exp(s - lse)
@@ -66,13 +89,12 @@ def block_bwd(dx, saved, sd, pre, r):
     ds = r(p * (dp - delta) / 8.0, "dS")
     dq = torch.matmul(ds, k)
     dk = torch.matmul(ds.transpose(-1, -2), q)
-    dqkv = r(torch.cat([O._merge_heads(dq), O._merge_heads(dk), O._merge_heads(dv)], dim=-1), "dqkv")
-    dh1 = dqkv @ sd[pre + "attn.in_proj_weight"]
+    dh1 = r.mm(torch.cat([O._merge_heads(dq), O._merge_heads(dk), O._merge_heads(dv)], dim=-1), "dqkv", sd[pre + "attn.in_proj_weight"])
     return dxm + O.layernorm_bwd(dh1, ln1[0], ln1[1], sd[pre + "ln_1.weight"])
 
 
-def run(sd, prompts, eot, dfeat_fn, heads, layers, enabled, split=()):
-    r = make_round(set(enabled), set(split))
+def run(sd, prompts, eot, dfeat_fn, heads, layers, enabled, split=(), mix=(), lo_fmt="e5m2"):
+    r = make_round(set(enabled), set(split), set(mix), lo_fmt)
     C, L, dt = prompts.shape
     x = prompts + sd["positional_embedding"][:L]
     saved = []
@@ -120,8 +142,8 @@ def main():
         f0, dx0 = run(sd, prompts, eot, dfeat_fn, heads, layers, [])
         g0 = O.scatter_prompt_grad(dx0, layout, (n_ctx, dt))
 
-        def report(tag, enabled, split=()):
-            f, dx = run(sd, prompts, eot, dfeat_fn, heads, layers, enabled, split)
+        def report(tag, enabled, split=(), mix=(), lo_fmt="e5m2"):
+            f, dx = run(sd, prompts, eot, dfeat_fn, heads, layers, enabled, split, mix, lo_fmt)
             g = O.scatter_prompt_grad(dx, layout, (n_ctx, dt))
             eg = float((g - g0).abs().max() / g0.abs().max())
             el2 = float((g - g0).norm() / g0.norm())
@@ -129,7 +151,15 @@ def main():
             print(f"{tag:34s} grad max-rel {eg:.2e}  L2-rel {el2:.2e}   feat {ef:.2e}")
             return eg
 
+        GEMM_A = ["h1", "o", "h2", "a", "dx_pr", "du", "dx_o", "dqkv"]
         report("all sites fp16", SITES)
+        report("all, split all", SITES, SITES)
+        report("split all, GEMM-A lo in e5m2 x W e4m3", SITES, SITES, GEMM_A)
+        report("split all, GEMM-A lo in e4m3 x W e4m3", SITES, SITES, GEMM_A, "e4m3")
+        report("mixed fwd GEMMs only", SITES, SITES, GEMM_A[:4])
+        report("mixed bwd GEMMs only", SITES, SITES, GEMM_A[4:])
+        if len(sys.argv) > 3 and sys.argv[3] == "mix":
+            return
         for s in SITES:
             report(f"only {s}", [s])
         report("forward sites only", SITES[:7])
