@@ -257,20 +257,21 @@ def main():
     sd = make_state_dict(arch, seed=1)
     # class prompts: the reference tokenizer's own ids for the BASELINE class lists (mvlpt_amd/data/class_prompts.npz)
     list_name = CP.BY_CLASS_COUNT.get(args.classes)
-    pre, task_counts = None, None
+    pre, task_counts, book = None, None, None
     if list_name is not None:
         pre, _ = CP.load_class_prompts(list_name, n_ctx, cut_contextlen=args.cut, context_length=arch.context_length)
         if args.multitask:
             task_counts = CP.task_class_counts(list_name)
             if len(task_counts) < 2:
                 raise SystemExit("--multitask needs a multitask class list (--classes 2191 or 1151)")
+            book = CP.MultitaskBook.from_list(list_name)      # real task names / class names / label offsets (trainers/mvlpt.py:585-645)
             cfg.DATASET.MULTITASK = cfg.DATASET.MULTITASK_LABEL_PERTASK = True
     elif args.multitask:
         raise SystemExit("--multitask needs a multitask class list (--classes 2191 or 1151)")
     n_batches = 4
     W, K = args.warmup, args.steps
     dm = SyntheticDataManager(cfg, args.classes, n_batches, task_class_counts=task_counts, device=dev, seed=1234 + rank,
-                              soft_labels=args.multitask)
+                              soft_labels=args.multitask, book=book)
     dm.pretokenized = pre
     dm.train_loader_x = _CyclingLoader(dm.train_loader_x, W + K + 1)
     trainer = MVLPT(cfg, dm=dm, clip_state_dict=sd)
@@ -386,7 +387,7 @@ def main():
                                     f"n_ctx={n_ctx} n_vpt={n_vpt}, text L={L_text}, class token middle"
                                     f"{', per-task mask + soft labels' if args.multitask else ''}"),
                        "text_positions_evaluated": (trainer.model.prompt_learner.max_eot + 1) if args.trim_eot else L_text,
-                       "loop": "TrainerX.run_epoch (reads one batch ahead)", "step_pipelining": bool(pipeline),
+                       "loop": "TrainerX.run_epoch = the plain Dassl loop `for batch in train_loader_x: forward_backward(batch)`; the one-batch look-ahead comes from the loader (LookAheadLoader, installed by MVLPT.build_data_loader)", "step_pipelining": bool(pipeline),
                        "grad_precision": args.grad_precision,
                        "per_gpu_batch": args.batch, "global_batch": B_global, "parallelism": f"dp{world}",
                        "text_tower": "class-sharded over ranks" if (args.shard_text and world > 1) else "replicated per GPU", "loss": round(loss, 5)},
@@ -435,7 +436,10 @@ def main():
                                                          "achieved_executed": round(gs["flops_executed"] / (gs["ms"] * 1e-3) / 1e12, 1),
                                                          "avg_launch_us": round(1e3 * gs["ms"] / gs["launches"], 2),
                                                          "note": "3 untimed steps, everything on one stream, no cross-step prefetch"}
-            line["kernel_ms_per_step"] = {k: round(v["ms"] / n_sampled, 3) for k, v in stats.items()}
+            # (three streams overlap in the timed region and concurrent kernels stretch each other: these are SUMS of
+            # per-launch durations per kernel class, not shares of the step, and may add up to more than ms_per_step)
+            line["kernel_duration_sums_ms_per_step"] = {k: round(v["ms"] / n_sampled, 3) for k, v in stats.items()}
+            line["kernel_duration_sums_ms_per_step"]["note"] = "sum of launch durations under 3 overlapping streams; can exceed ms_per_step"
             # executed (not algorithmic) step-level fraction: GEMM FLOPs actually issued per step (CLS-only / EOT-only last
             # blocks skip work the reference computes and never reads; split-precision GEMMs issue twice their 2MNK)
             # plus the attention FLOPs at their algorithmic count
@@ -446,6 +450,12 @@ def main():
             line["text_trimmed_to_eot"] = trim_line
         if world == 1 and not args.no_cpu_baseline and args.method == "coop" and pre is not None:
             line["cpu_baseline"] = cpu_baseline_images_per_sec(arch, sd, args.classes, L_text, n_ctx, pre)
+            if is_headline:
+                # configs[0], the reference's own CPU-runnable case (ViT-B/32, B = 32, same class list)
+                from mvlpt_amd.weights import ARCHS as _A, make_state_dict as _mk
+                a32 = _A["ViT-B/32"]
+                line["cpu_baseline_cfg1"] = cpu_baseline_images_per_sec(a32, _mk(a32, seed=cfg.SEED), args.classes, L_text, n_ctx, pre, B_cpu=32)
+                line["cpu_baseline_cfg1"]["config"] = "BASELINE configs[0]: CoOp ViT-B/32, 100 classes, n_ctx=16, L=77, full batch of 32"
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -30,9 +30,23 @@ X_TOKEN = 343                            # "X" placeholder word (trainers/mvlpt.
 
 
 # ------------------------------------------------------------------------------------------------ tokenisation
+_DEFAULT_TOKENIZER = None
+
+
+def default_tokenizer():
+    """The real thing: own byte-level BPE over the shipped merge table (mvlpt_amd/tokenizer.py), ids bit-exact against the
+    reference tokenizer (tests/test_tokenizer.py)."""
+    global _DEFAULT_TOKENIZER
+    if _DEFAULT_TOKENIZER is None:
+        from .tokenizer import BPETokenizer
+        _DEFAULT_TOKENIZER = BPETokenizer()
+    return _DEFAULT_TOKENIZER
+
+
 class SyntheticTokenizer:
-    """Offline stand-in for clip.simple_tokenizer (the BPE vocabulary cannot be shipped to the GPU box in round 1;
-    SURVEY §8f row 4).  One pseudo-token per whitespace-separated word (stable hash), which reproduces the
+    """Hash-based stand-in for clip.simple_tokenizer, kept for tests that want token ids independent of any table (rounds 1-2
+    used it wherever the BPE merge table was missing; the table ships now and `FrozenCLIP` defaults to the real tokenizer).
+    One pseudo-token per whitespace-separated word (stable hash), which reproduces the
     *structure* the hot path depends on: [SOT, prefix words…, name words…, '.', EOT, 0…] and name_lens."""
 
     def encode(self, text: str) -> List[int]:
@@ -107,7 +121,7 @@ class FrozenCLIP:
         self.device = self.engine.device
         self.context_length = self.arch.context_length
         self.logit_scale = state_dict["logit_scale"].detach().float().to(self.device)     # frozen, clip/model.py:291
-        self.tokenizer = tokenizer or SyntheticTokenizer()
+        self.tokenizer = tokenizer or default_tokenizer()
         self._token_embedding = state_dict.get("token_embedding.weight")
         self._token_seed = token_seed
         self.dtype = torch.float32   # dtype of the prompt parameters (see module docstring)
@@ -544,6 +558,13 @@ class CustomCLIP(nn.Module):
             ev.record(st)
         self._prefetched = (image.data_ptr(), tuple(image.shape), image._version, feat, ev)
         return True
+
+    def drop_prefetch(self) -> None:
+        """Forget a prefetched image forward that nobody will pick up (the loop left the loader early): the main stream
+        waits for the side stream so that the image-tower workspace is quiescent for whatever runs next."""
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None:
+            torch.cuda.current_stream().wait_event(pre[4])
 
     def forward(self, image, task=None):
         coop_emb, vpt_emb, vpt_emb_deep = self.prompt_learner.forward_mvlpt_proj(self.dtype)

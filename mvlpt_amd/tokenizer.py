@@ -3,9 +3,10 @@
 Own implementation of the published algorithm the reference uses (clip/simple_tokenizer.py:62-132 and
 `clip.tokenize`, clip/clip.py:187-223): text -> lower-case, whitespace-collapsed -> regex word split -> UTF-8
 bytes mapped to printable code points -> greedy lowest-rank pair merging -> vocabulary ids; SOT = 49406, EOT = 49407.
-The 1.3 MB merge table (`bpe_simple_vocab_16e6.txt.gz`, distributed with CLIP) is DATA that is not shipped here:
-pass its path (or set MVLPT_BPE_VOCAB).  Without it use `mvlpt_amd.model.SyntheticTokenizer` (bench / tests).
-Parity pin: tests/golden/tokens.npz, generated with the reference tokenizer.
+The merge table is DATA shipped with the package: `mvlpt_amd/data/bpe_merges.txt.gz` = the 48 894 merges CLIP keeps of its
+`bpe_simple_vocab_16e6.txt.gz` (oracle/make_bpe_table.py); CLIP's own file is accepted too (path argument or MVLPT_BPE_VOCAB).
+Parity pin: tests/golden/tokens.npz and the four class-list tables of mvlpt_amd/data/class_prompts.npz, all generated with
+the reference tokenizer.
 """
 from __future__ import annotations
 
@@ -39,18 +40,26 @@ def _byte_symbols() -> Dict[int, str]:
     return table
 
 
+SHIPPED_MERGES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "bpe_merges.txt.gz")
+
+
 class BPETokenizer:
     def __init__(self, vocab_path: str | None = None):
-        vocab_path = vocab_path or os.environ.get("MVLPT_BPE_VOCAB")
-        if not vocab_path or not os.path.isfile(vocab_path):
-            raise FileNotFoundError("BPE merge table not found: pass the path of CLIP's bpe_simple_vocab_16e6.txt.gz "
-                                    "or set MVLPT_BPE_VOCAB")
+        vocab_path = vocab_path or os.environ.get("MVLPT_BPE_VOCAB") or SHIPPED_MERGES
+        if not os.path.isfile(vocab_path):
+            raise FileNotFoundError(f"BPE merge table not found: {vocab_path} (shipped: {SHIPPED_MERGES}; CLIP's own "
+                                    "bpe_simple_vocab_16e6.txt.gz works too: pass its path or set MVLPT_BPE_VOCAB)")
         with gzip.open(vocab_path, "rt", encoding="utf-8") as f:
             lines = f.read().split("\n")
-        merges: List[Tuple[str, str]] = [tuple(l.split()) for l in lines[1:1 + N_MERGES]]
+        if lines and "#version" in lines[0]:
+            lines = lines[1:]                 # CLIP's file opens with a version header; the shipped table has none
+        merges: List[Tuple[str, str]] = [tuple(l.split()) for l in lines[:N_MERGES]]
+        if len(merges) != N_MERGES or any(len(m) != 2 for m in merges):
+            raise ValueError(f"{vocab_path}: expected {N_MERGES} merges of two symbols")
         symbols = list(_byte_symbols().values())
         vocab = symbols + [s + "</w>" for s in symbols] + ["".join(m) for m in merges] + [SOT, EOT]
         self.encoder = {tok: i for i, tok in enumerate(vocab)}
+        self.decoder = vocab
         self.rank = {m: i for i, m in enumerate(merges)}
         self._cache: Dict[str, List[str]] = {}
 
@@ -90,6 +99,21 @@ class BPETokenizer:
             mapped = "".join(sym[b] for b in w.encode("utf-8"))
             ids.extend(self.encoder[u] for u in self._merge_word(mapped))
         return ids
+
+    def decode(self, ids: Sequence[int]) -> str:
+        """Inverse of `encode` up to whitespace / case (clip/simple_tokenizer.py:129-132): word ends become single spaces."""
+        rev = {c: b for b, c in _byte_symbols().items()}
+        out = bytearray()
+        for i in ids:
+            piece = self.decoder[int(i)]
+            if piece in (SOT, EOT):
+                out += piece.encode() + b" "
+                continue
+            end = piece.endswith("</w>")
+            out += bytes(rev[c] for c in (piece[:-4] if end else piece))
+            if end:
+                out += b" "
+        return out.decode("utf-8", errors="replace")
 
     def tokenize(self, texts: Union[str, Sequence[str]], context_length: int = 77, truncate: bool = False) -> torch.Tensor:
         """`clip.tokenize` contract: LongTensor [n, context_length], [SOT] + ids + [EOT], zero padded."""

@@ -197,32 +197,34 @@ class TrainerX:
                 self.save_model(self.epoch, self.output_dir)
 
     def run_epoch(self):
-        """One pass over train_loader_x (Dassl run_epoch).  The loader is read ONE BATCH AHEAD: while
-        step i runs, `self.next_batch` holds batch i+1, so a trainer whose forward has a batch-independent half (MVLPT
-        without visual prompts: the image features are a pure function of the image) can start it underneath the
-        current backward.  `forward_backward(batch)` keeps the reference's one-argument signature.
+        """One pass over train_loader_x: the plain Dassl loop — `for batch_idx, batch in
+        enumerate(loader): forward_backward(batch)`.  The one-batch look-ahead that lets `forward_backward` start the next
+        step's image tower underneath this step's backward does NOT live here: it comes from the loader itself
+        (`LookAheadLoader`, installed by `MVLPT.build_data_loader`), so an unmodified Dassl `run_epoch` gets it too.
         `self.batch_hook(batch_idx)` (optional) runs before every step: bench.py uses it to place its timers."""
         self.set_model_mode("train")
         self.num_batches = len(self.train_loader_x)
         t0 = time.time()
-        it = iter(self.train_loader_x)
-        nxt = next(it, None)
+        summary = None
         self.batch_idx = -1
-        while nxt is not None:
-            batch, nxt = nxt, next(it, None)
-            self.batch_idx += 1
-            self.next_batch = nxt
-            if self.batch_hook is not None and self.batch_hook(self.batch_idx) is False:
-                break
-            summary = self.forward_backward(batch)
-            if (self.batch_idx + 1) % self.cfg.TRAIN.PRINT_FREQ == 0 and self.rank == 0:
-                vals = {k: (float(v) if torch.is_tensor(v) else v) for k, v in summary.items()}
-                if not math.isfinite(vals["loss"]):
-                    raise FloatingPointError("Loss is infinite or NaN!")
-                print(f"epoch [{self.epoch + 1}/{self.max_epoch}] batch [{self.batch_idx + 1}/{self.num_batches}] "
-                      f"time {time.time() - t0:.2f}s " + " ".join(f"{k} {v:.4f}" for k, v in vals.items()))
+        try:
+            for self.batch_idx, batch in enumerate(self.train_loader_x):
+                if self.batch_hook is not None and self.batch_hook(self.batch_idx) is False:
+                    break
+                summary = self.forward_backward(batch)
+                if (self.batch_idx + 1) % self.cfg.TRAIN.PRINT_FREQ == 0 and self.rank == 0:
+                    vals = {k: (float(v) if torch.is_tensor(v) else v) for k, v in summary.items()}
+                    if not math.isfinite(vals["loss"]):
+                        raise FloatingPointError("Loss is infinite or NaN!")
+                    print(f"epoch [{self.epoch + 1}/{self.max_epoch}] batch [{self.batch_idx + 1}/{self.num_batches}] "
+                          f"time {time.time() - t0:.2f}s " + " ".join(f"{k} {v:.4f}" for k, v in vals.items()))
+        finally:
+            self.end_of_epoch_loop()
+        return summary
+
+    def end_of_epoch_loop(self):
+        """The loop left the loader (exhausted, hook break, exception): nothing of the look-ahead may survive it."""
         self.next_batch = None
-        return summary if self.batch_idx >= 0 else None
 
     # hooks the concrete trainer provides
     def check_cfg(self, cfg):
@@ -238,22 +240,60 @@ class TrainerX:
         raise NotImplementedError
 
 
+# ------------------------------------------------------------------------------------------------ look-ahead
+class LookAheadLoader:
+    """Wraps a train loader so that ANY loop over it — Dassl's own `run_epoch` included — runs one batch ahead: while the
+    consumer works on batch i, `owner.next_batch` holds batch i+1 (None on the last one).  `MVLPT.forward_backward(batch)`
+    (the reference's one-argument signature, trainers/mvlpt.py:910) reads it to upload batch i+1 and to start its image
+    tower underneath the backward of step i.  Length, attributes (`dataset`, `batch_size`, ...) pass through."""
+
+    def __init__(self, loader, owner):
+        self.loader, self.owner = loader, owner
+        self.hits = 0                      # batches that were handed out with a successor already fetched
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __getattr__(self, name):
+        return getattr(self.loader, name)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        nxt = next(it, None)
+        try:
+            while nxt is not None:
+                batch, nxt = nxt, next(it, None)
+                self.owner.next_batch = nxt
+                self.hits += nxt is not None
+                yield batch
+        finally:
+            self.owner.next_batch = None
+
+
 # ------------------------------------------------------------------------------------------------ synthetic data
 class SyntheticDataManager:
     """Shape-contract stand-in for MVLPTCOOPDataManager (trainers/mvlpt.py:585-671): N(0,1) images, uniform labels,
     optional task ids with labels drawn inside the task's class range."""
 
     def __init__(self, cfg, num_classes: int, steps_per_epoch: int, task_class_counts=None, device="cpu", seed=1234,
-                 soft_labels=False, elevater=False, metric_names=None):
+                 soft_labels=False, elevater=False, metric_names=None, book=None):
+        """`book` (mvlpt_amd.class_prompts.MultitaskBook): real per-dataset class lists — task names, class names and the
+        label offsets come from it (trainers/mvlpt.py:585-645); only the images and the label draws stay synthetic."""
+        if book is not None:
+            assert num_classes == book.num_classes
+            task_class_counts = list(book.num_classes_list)
         self.num_classes = self._num_classes = num_classes
-        self.classnames = [f"class {i}" for i in range(num_classes)]
-        self.lab2cname = {i: n for i, n in enumerate(self.classnames)}
+        self.classnames = list(book.classnames) if book is not None else [f"class {i}" for i in range(num_classes)]
+        self.lab2cname = dict(book.lab2cname) if book is not None else {i: n for i, n in enumerate(self.classnames)}
         self.dataset = self
         self.num_source_domains = 1
         self._task_names, self._labelmap = [], {}
         self.task_class_counts = task_class_counts
         self._task_class_idx, self._id2task = {}, {}
-        if task_class_counts:
+        if book is not None:
+            self._task_names, self._labelmap = list(book._task_names), dict(book._labelmap)
+            self._id2task, self._task_class_idx = dict(book._id2task), dict(book._task_class_idx)
+        elif task_class_counts:
             self._task_names = [f"task{i}" for i in range(len(task_class_counts))]
             self._labelmap = {n: list(range(c)) for n, c in zip(self._task_names, task_class_counts)}
             self._id2task = dict(enumerate(self._task_names))                       # trainers/mvlpt.py:780-790
@@ -317,7 +357,9 @@ class MVLPT(TrainerX):
         dm = self._dm_arg
         if dm is None:
             raise ValueError("pass a data manager (e.g. SyntheticDataManager); dataset readers are out of scope")
-        self.train_loader_x, self.train_loader_u = dm.train_loader_x, dm.train_loader_u
+        # the look-ahead lives in the loader (see LookAheadLoader): a plain `for batch in self.train_loader_x` pipelines
+        self.train_loader_x = LookAheadLoader(dm.train_loader_x, self) if self.cfg.TRAINER.MVLPT.STEP_PIPELINING else dm.train_loader_x
+        self.train_loader_u = dm.train_loader_u
         self.val_loader, self.test_loader = dm.val_loader, dm.test_loader
         self.num_classes, self.num_source_domains, self.lab2cname = dm.num_classes, dm.num_source_domains, dm.lab2cname
         self.dm = dm
@@ -377,6 +419,12 @@ class MVLPT(TrainerX):
         if (self.batch_idx + 1) == self.num_batches:
             self.update_lr()
         return loss_summary
+
+    def end_of_epoch_loop(self):
+        super().end_of_epoch_loop()
+        self._parsed_ahead = None
+        if getattr(self, "model", None) is not None:
+            self.model.drop_prefetch()
 
     def parse_batch_train(self, batch):
         if self.cfg.DATASET.COOP:

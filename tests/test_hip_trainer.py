@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def make_trainer(tmp_path, method="coop", classes=6, tasks=None, steps=4, B=8, elevater=False, metric_names=None):
+def make_trainer(tmp_path, method="coop", classes=6, tasks=None, steps=4, B=8, elevater=False, metric_names=None, pipelining=True):
     from mvlpt_amd.config import get_cfg_default
     from mvlpt_amd.trainer import MVLPT, SyntheticDataManager
     from mvlpt_amd.weights import ARCHS, make_state_dict
@@ -30,6 +30,7 @@ def make_trainer(tmp_path, method="coop", classes=6, tasks=None, steps=4, B=8, e
         cfg.DATASET.MULTITASK = True
         cfg.DATASET.MULTITASK_LABEL_PERTASK = True
     cfg.DATASET.COOP = not elevater
+    cfg.TRAINER.MVLPT.STEP_PIPELINING = pipelining
     dm = SyntheticDataManager(cfg, classes, steps, task_class_counts=tasks, device="cuda", seed=3, elevater=elevater,
                               metric_names=metric_names)
     return MVLPT(cfg, dm=dm, clip_state_dict=make_state_dict(ARCHS["tiny"], seed=9))
@@ -133,6 +134,44 @@ def test_step_pipelining_is_transparent(tmp_path):
         runs.append((losses, tr.model.prompt_learner.ctx.detach().cpu().clone()))
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     assert torch.equal(runs[0][1], runs[1][1])
+
+
+def test_lookahead_reaches_a_plain_dassl_loop(tmp_path):
+    """the look-ahead must not depend on this repo's run_epoch.  A PLAIN loop over the trainer's loader
+    — `for batch in loader: forward_backward(batch)`, what Dassl's own run_epoch does — gets the prefetch, because
+    MVLPT.build_data_loader wraps train_loader_x in a LookAheadLoader."""
+    from mvlpt_amd.trainer import LookAheadLoader
+    torch.manual_seed(0)
+    tr = make_trainer(tmp_path, "coop")
+    assert isinstance(tr.train_loader_x, LookAheadLoader) and len(tr.train_loader_x) == 4
+    hits = []
+    orig = tr.model.engine.image_fwd
+    tr.model.engine.image_fwd = lambda *a, **k: (hits.append(torch.cuda.current_stream().cuda_stream), orig(*a, **k))[1]
+    tr.set_model_mode("train")
+    tr.num_batches = len(tr.train_loader_x)
+    losses = []
+    for tr.batch_idx, batch in enumerate(tr.train_loader_x):          # no run_epoch, no next_batch bookkeeping here
+        losses.append(float(tr.forward_backward(batch)["loss"]))
+    main = torch.cuda.current_stream().cuda_stream
+    assert len(hits) == 4 and [h != main for h in hits] == [False, True, True, True], hits
+    assert tr.train_loader_x.hits == 3 and tr.next_batch is None
+    # same numbers as the un-pipelined trainer
+    torch.manual_seed(0)
+    tr2 = make_trainer(tmp_path, "coop", pipelining=False)
+    assert not isinstance(tr2.train_loader_x, LookAheadLoader)
+    tr2.set_model_mode("train")
+    tr2.num_batches = len(tr2.train_loader_x)
+    l2 = []
+    for tr2.batch_idx, batch in enumerate(tr2.train_loader_x):
+        l2.append(float(tr2.forward_backward(batch)["loss"]))
+    assert losses == l2
+    # leaving the loop early drops the pending prefetch instead of leaving it for an unrelated forward
+    it = iter(tr.train_loader_x)
+    tr.forward_backward(next(it))
+    assert tr.model._prefetched is not None
+    it.close()
+    tr.end_of_epoch_loop()
+    assert tr.model._prefetched is None and tr._parsed_ahead is None and tr.next_batch is None
 
 
 def test_three_reference_train_steps_on_the_hip_engine(tmp_path):

@@ -168,3 +168,27 @@ def test_bench_clock_sampler_reads_hwmon(tmp_path, monkeypatch):
     s = bench._ClockSampler()
     s.start()
     assert s.stop() is None
+
+
+def test_lookahead_loader_semantics():
+    """LookAheadLoader (the place the one-batch look-ahead lives, so that an unmodified Dassl run_epoch gets it): while the
+    consumer holds batch i, owner.next_batch is batch i+1; None on the last batch, after exhaustion and after an early exit."""
+    from mvlpt_amd.trainer import LookAheadLoader
+
+    class Owner:
+        next_batch = "stale"
+
+    class Loader(list):
+        batch_size = 7
+
+    o = Owner()
+    la = LookAheadLoader(Loader(["a", "b", "c"]), o)
+    assert len(la) == 3 and la.batch_size == 7
+    seen = [(b, o.next_batch) for b in la]
+    assert seen == [("a", "b"), ("b", "c"), ("c", None)] and o.next_batch is None and la.hits == 2
+    assert [(b, o.next_batch) for b in la] == seen                       # re-iterable (one pass per epoch)
+    it = iter(la)
+    assert next(it) == "a" and o.next_batch == "b"
+    it.close()                                                           # a hook broke out of the loop
+    assert o.next_batch is None
+    assert list(LookAheadLoader(Loader([]), o)) == [] and o.next_batch is None
