@@ -207,7 +207,10 @@ def main():
     ap.add_argument("--no-trim-extra", action="store_true", help="skip the extra untimed-for-the-headline pass that reports the --trim-eot rate")
     ap.add_argument("--no-step-pipelining", action="store_true",
                     help="do not compute the next batch's image features underneath the current backward")
-    ap.add_argument("--shard-text", action="store_true", help="class-shard the text tower over the ranks (many-class configs)")
+    ap.add_argument("--shard-text", dest="shard_text", action="store_true", default=None,
+                    help="class-shard the text tower over the ranks; default: on when --gpus > 1 and --classes >= 1000 (the text tower costs "
+                         "C * L tokens per step on EVERY rank otherwise), off for small class lists")
+    ap.add_argument("--no-shard-text", dest="shard_text", action="store_false", help="replicate the text tower on every rank")
     ap.add_argument("--multitask", action="store_true",
                     help="ELEVATER-style multitask batch: per-task logit mask + soft labels (needs a multitask class list: 2191 / 1151 classes)")
     ap.add_argument("--grad-precision", default="split_grad", choices=["split_grad", "fast"],
@@ -276,6 +279,8 @@ def main():
     dm.train_loader_x = _CyclingLoader(dm.train_loader_x, W + K + 1)
     trainer = MVLPT(cfg, dm=dm, clip_state_dict=sd)
     trainer.model.trim_text_to_eot = args.trim_eot
+    if args.shard_text is None:
+        args.shard_text = world > 1 and args.classes >= 1000 and n_ctx > 0
     if args.shard_text and world > 1:
         trainer.model.enable_class_sharding(rank, world)
     L_text = trainer.model.prompt_learner.tokenized_prompts.shape[1]

@@ -57,6 +57,54 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+class FlatGradients:
+    """ONE persistent fp32 buffer that every parameter's `.grad` is a view of (what DDP calls gradient_as_bucket_view).
+    Autograd accumulates into an existing `.grad` in place and `zero_grad(set_to_none=False)` zeroes in place, so the views
+    survive the training loop; the per-step exchange is then a single in-place collective on `flat` — no torch.cat, no
+    copy back, no scaling launch (RCCL averages itself: ReduceOp.AVG).  N > 1 adds exactly ONE launch per step."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views: List[torch.Tensor] = []
+        off = 0
+        for p in self.params:
+            v = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+            self.views.append(v)
+        self.attach()
+
+    def attach(self) -> None:
+        for p, v in zip(self.params, self.views):
+            if p.dtype != torch.float32:
+                raise TypeError("FlatGradients: fp32 master parameters expected")
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            p.grad = v
+
+    def intact(self) -> bool:
+        """False once somebody replaced a `.grad` (zero_grad(set_to_none=True), a fresh tensor assigned by hand)."""
+        return all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
+
+    def zero_(self) -> None:
+        if not self.intact():
+            self.attach()
+        self.flat.zero_()
+
+    def all_reduce_mean_(self, world_size: int) -> None:
+        if world_size <= 1 or self.flat.numel() == 0:
+            return
+        if not self.intact():
+            self.attach()
+        if _host_staged() or not self.flat.is_cuda:
+            all_reduce_sum_(self.flat)                      # gloo: no AVG; host-staged in the one-GPU debug mode
+            self.flat.mul_(1.0 / world_size)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+
+
 def all_reduce_gradients(params: Iterable[torch.nn.Parameter], world_size: int) -> None:
     """grad <- mean over ranks, through one flat buffer (each rank's loss is the mean over its own slice, all
     slices have the same size, so the mean of rank gradients is the gradient of the global-batch mean loss)."""

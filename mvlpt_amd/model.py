@@ -318,40 +318,60 @@ def class_shard_bounds(n_cls: int, world: int):
     return [(r * base + min(r, rem), (r + 1) * base + min(r + 1, rem)) for r in range(world)]
 
 
-def _gather_class_shards(loc: torch.Tensor, bounds, cmax: int) -> torch.Tensor:
-    """all-gather of per-rank text features [c_r, e] (c_r <= cmax) -> [n_cls, e] (RCCL over xGMI: <= 4.5 MB)."""
-    import torch.distributed as dist
-    e, world = loc.shape[1], len(bounds)
-    pad = torch.zeros(cmax, e, device=loc.device, dtype=loc.dtype)
-    pad[:loc.shape[0]] = loc
-    if dist.get_backend() == "gloo":          # CPU tests / one-GPU debug mode: host-staged all-reduce of disjoint slots
-        out = torch.zeros(world * cmax, e, dtype=loc.dtype)
-        r = dist.get_rank()
-        out[r * cmax:(r + 1) * cmax] = pad.cpu()
-        dist.all_reduce(out, op=dist.ReduceOp.SUM)
-        out = out.to(loc.device)
-    else:
-        out = torch.empty(world * cmax, e, device=loc.device, dtype=loc.dtype)
-        dist.all_gather_into_tensor(out, pad)
-    return torch.cat([out[r * cmax:r * cmax + (hi - lo)] for r, (lo, hi) in enumerate(bounds)], dim=0)
+class ClassShard:
+    """Class-sharded text tower (collective 2): rank r encodes classes bounds[r] only.  Every rank contributes
+    a slot of `cmax` rows (the largest shard) to ONE all_gather_into_tensor of the features and receives its slot of ONE
+    reduce_scatter_tensor (sum) of their gradients, both on persistent buffers.  Shards of equal size need no other launch
+    (the gathered buffer IS the [n_cls, e] feature matrix); ragged shards (n_cls % world != 0) add one index_select /
+    index_copy with index tensors built once.  Per step N > 1 adds: 1 copy + 1 all-gather (+1), 1 reduce-scatter (+1)."""
 
+    def __init__(self, rank: int, bounds, device, dtype=torch.float32):
+        self.rank, self.bounds, self.world = rank, bounds, len(bounds)
+        self.cmax = max(hi - lo for lo, hi in bounds)
+        self.lo, self.hi = bounds[rank]
+        self.even = all(hi - lo == self.cmax for lo, hi in bounds)
+        self.device, self.dtype = device, dtype
+        self._e = None
+        # slot row of every class (class c of rank r sits at r * cmax + (c - lo_r))
+        self.slot_of_class = torch.cat([torch.arange(hi - lo) + r * self.cmax for r, (lo, hi) in enumerate(bounds)]).to(device)
 
-def _scatter_class_grads(dtxt: torch.Tensor, bounds, cmax: int, rank: int) -> torch.Tensor:
-    """reduce-scatter (sum) of d txt [n_cls, e] back to the class owners -> [hi-lo, e]."""
-    import torch.distributed as dist
-    e, world = dtxt.shape[1], len(bounds)
-    buf = torch.zeros(world * cmax, e, device=dtxt.device, dtype=dtxt.dtype)
-    for r, (lo, hi) in enumerate(bounds):
-        buf[r * cmax:r * cmax + (hi - lo)] = dtxt[lo:hi]
-    if dist.get_backend() == "gloo":          # CPU tests / one-GPU debug mode: gloo has no reduce_scatter; host-staged
-        h = buf.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM)
-        own = h[rank * cmax:(rank + 1) * cmax].to(dtxt.device)
-    else:
-        own = torch.empty(cmax, e, device=dtxt.device, dtype=dtxt.dtype)
-        dist.reduce_scatter_tensor(own, buf, op=dist.ReduceOp.SUM)
-    lo, hi = bounds[rank]
-    return own[:hi - lo].contiguous()
+    def _buffers(self, e: int):
+        if self._e != e:
+            z = lambda rows: torch.zeros(rows, e, device=self.device, dtype=self.dtype)
+            self.gin, self.gout, self.sin, self.sout = z(self.cmax), z(self.world * self.cmax), z(self.world * self.cmax), z(self.cmax)
+            self._e = e
+        return self.gin, self.gout, self.sin, self.sout
+
+    def gather(self, loc: torch.Tensor) -> torch.Tensor:
+        """per-rank text features [c_r, e] -> [n_cls, e] on every rank (RCCL over xGMI: <= 4.5 MB)."""
+        import torch.distributed as dist
+        gin, gout, _, _ = self._buffers(loc.shape[1])
+        gin[:loc.shape[0]].copy_(loc)                     # pad rows (ragged shards) stay zero
+        if dist.get_backend() == "gloo":                  # CPU tests / one-GPU debug mode: host-staged, disjoint slots summed
+            h = torch.zeros(gout.shape, dtype=gout.dtype)
+            h[self.rank * self.cmax:(self.rank + 1) * self.cmax] = gin.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            gout.copy_(h)
+        else:
+            dist.all_gather_into_tensor(gout, gin)
+        return gout if self.even else gout.index_select(0, self.slot_of_class)
+
+    def scatter_grads(self, dtxt: torch.Tensor) -> torch.Tensor:
+        """reduce-scatter (sum over ranks) of d txt [n_cls, e] back to the class owners -> [hi - lo, e]."""
+        import torch.distributed as dist
+        _, _, sin, sout = self._buffers(dtxt.shape[1])
+        if self.even:
+            src = dtxt.contiguous()
+        else:
+            sin.index_copy_(0, self.slot_of_class, dtxt)  # pad rows were zeroed at allocation and are never written
+            src = sin
+        if dist.get_backend() == "gloo":                  # gloo has no reduce_scatter: host-staged all-reduce
+            h = src.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            sout.copy_(h[self.rank * self.cmax:(self.rank + 1) * self.cmax])
+        else:
+            dist.reduce_scatter_tensor(sout, src, op=dist.ReduceOp.SUM)
+        return sout[:self.hi - self.lo]
 
 
 # ------------------------------------------------------------------------------------------------ autograd bridge
@@ -405,15 +425,28 @@ class _PromptedClipFn(torch.autograd.Function):
         shard = model._class_shard if (run_text and coop_emb is not None) else None
         side = model._side_stream if (run_text and model.overlap_towers and shard is None) else None
         if shard is not None:
-            # Class-sharded text tower (collective 2): this rank encodes classes [lo, hi) only, the
-            # features are all-gathered; the backward reduce-scatters d(txt) back to the owners.
-            img = image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
-            rank, bounds, cmax = shard
-            lo, hi = bounds[rank]
+            # Class-sharded text tower (ClassShard): this rank encodes classes [lo, hi) only and the features are
+            # all-gathered; the backward reduce-scatters d(txt) back to the owners.  Tower and collective run on the second
+            # stream underneath the image tower, exactly like the replicated text tower below.
+            lo, hi = shard.lo, shard.hi
             ctx_loc = coop_emb if coop_emb.dim() == 2 else coop_emb[lo:hi]
-            loc = eng.text_fwd(pl.token_prefix[lo:hi], suffix[lo:hi], ctx_loc, layout[lo:hi], pl.eot[lo:hi],
-                               save_for_bwd=need_txt)
-            txt = _gather_class_shards(loc, bounds, cmax)
+
+            def text_side():
+                loc = eng.text_fwd(pl.token_prefix[lo:hi], suffix[lo:hi], ctx_loc, layout[lo:hi], pl.eot[lo:hi],
+                                   save_for_bwd=need_txt)
+                return shard.gather(loc)
+            side_s = model._side_stream if model.overlap_towers else None
+            if side_s is not None:
+                main = torch.cuda.current_stream()
+                side_s.wait_stream(main)
+                with torch.cuda.stream(side_s):
+                    txt = text_side()
+                img = image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
+                main.wait_stream(side_s)
+                txt.record_stream(main)
+            else:
+                img = image_fwd(image, vpt_emb, vpt_deep_emb, save_for_bwd=need_img)
+                txt = text_side()
         elif side is not None:
             # The two towers are independent until the logits: the text tower (few, small launches that cannot
             # fill 256 CUs) runs on a second HIP stream underneath the image tower's large GEMMs.
@@ -433,7 +466,7 @@ class _PromptedClipFn(torch.autograd.Function):
         elif coop_emb is None:
             model._const_text_features = txt     # no text context: features are constants
         if ver is not None:
-            model._eval_text_cache = (ver, txt)
+            model._eval_text_cache = (ver, txt.clone() if shard is not None else txt)   # (a gathered txt lives in a reused buffer)
         if coop_emb is not None:
             model._const_text_features = None    # only the no-context case may persist across training steps
         logits = eng.logits_fwd(img, txt, model.logit_scale_exp, task_lo, task_hi)
@@ -457,11 +490,10 @@ class _PromptedClipFn(torch.autograd.Function):
         dimg, dtxt = eng.logits_bwd(dlogits.contiguous(), fctx.need_img, fctx.need_txt)
         dctx = dvpt = ddeep = None
         if fctx.need_txt and fctx.shard is not None:
-            rank, bounds, cmax = fctx.shard
-            lo, hi = bounds[rank]
+            lo, hi = fctx.shard.lo, fctx.shard.hi
             # sum over ranks of d(local loss)/d(txt) for the classes this rank owns; the trainer's gradient
             # all-reduce (mean over ranks) then yields d(global mean loss)/d(ctx) summed over all class shards
-            own = _scatter_class_grads(dtxt, bounds, cmax, rank)
+            own = fctx.shard.scatter_grads(dtxt)
             dloc = eng.text_bwd(own)
             if len(fctx.ctx_shape) == 3:                      # class-specific contexts: only the owned rows are non-zero
                 dctx = torch.zeros(fctx.ctx_shape, device=dloc.device, dtype=dloc.dtype)
@@ -536,8 +568,7 @@ class CustomCLIP(nn.Module):
         C = self.prompt_learner.n_cls
         if world > C:
             raise ValueError(f"class sharding needs at least one class per rank ({C} classes, {world} ranks)")
-        bounds = class_shard_bounds(C, world)
-        self._class_shard = (rank, bounds, max(hi - lo for lo, hi in bounds))
+        self._class_shard = ClassShard(rank, class_shard_bounds(C, world), self.clip_model.device)
 
     def prefetch_image_features(self, image) -> bool:
         """Software pipelining across steps: with no visual prompts the image tower is a pure function of the image

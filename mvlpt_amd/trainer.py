@@ -116,6 +116,7 @@ class TrainerX:
 
     def __init__(self, cfg: CfgNode):
         self._models, self._optims, self._scheds = OrderedDict(), OrderedDict(), OrderedDict()
+        self._flat_grads = {}
         self.cfg = cfg
         self.rank, self.world_size, self.local_rank = dist_utils.rank_info()
         self.device = torch.device(f"cuda:{self.local_rank}") if torch.cuda.is_available() else torch.device("cpu")
@@ -149,7 +150,10 @@ class TrainerX:
 
     def model_zero_grad(self, names=None):
         for n in self.get_model_names(names):
-            if self._optims[n] is not None:
+            flat = getattr(self, "_flat_grads", {}).get(n)
+            if flat is not None:
+                flat.zero_()                      # one launch: every .grad is a view of this buffer
+            elif self._optims[n] is not None:
                 self._optims[n].zero_grad(set_to_none=False)
 
     def model_backward(self, loss):
@@ -169,9 +173,20 @@ class TrainerX:
         self.model_update(names)
 
     def sync_gradients(self, names=None):
+        """The one exchange of the data-parallel step (replaces nn.DataParallel's gather, trainers/mvlpt.py:877-880): a single
+        in-place all-reduce (mean) of the flat gradient buffer the parameters' .grad alias."""
         if self.world_size > 1:
             for n in self.get_model_names(names):
-                dist_utils.all_reduce_gradients(self._models[n].parameters(), self.world_size)
+                flat = getattr(self, "_flat_grads", {}).get(n)
+                if flat is not None:
+                    flat.all_reduce_mean_(self.world_size)
+                else:
+                    dist_utils.all_reduce_gradients(self._models[n].parameters(), self.world_size)
+
+    def flatten_gradients(self, name):
+        """Give the registered model's parameters one persistent flat gradient buffer (distributed.FlatGradients)."""
+        self._flat_grads[name] = dist_utils.FlatGradients(self._models[name].parameters())
+        return self._flat_grads[name]
 
     # -- checkpoints (Dassl format: state_dict, epoch, optimizer, scheduler, val_result)
     def save_model(self, epoch, directory, is_best=False, val_result=None, model_name=""):
@@ -389,6 +404,7 @@ class MVLPT(TrainerX):
         self.optim = build_optimizer(self.model.prompt_learner, cfg.OPTIM)   # NOTE: only the prompt learner (:869)
         self.sched = build_lr_scheduler(self.optim, cfg.OPTIM)
         self.register_model("prompt_learner", self.model.prompt_learner, self.optim, self.sched)
+        self.flatten_gradients("prompt_learner")      # zero_grad = 1 launch; N > 1: one in-place all-reduce, nothing else
         self.scaler = None    # the HIP backward scales its 16-bit activation gradients internally
 
     def forward_backward(self, batch):

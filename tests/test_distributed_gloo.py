@@ -39,13 +39,29 @@ def _worker(rank, world, port, ret):
     loss_fn(X[rank * 4:(rank + 1) * 4]).backward()
     D.all_reduce_gradients(params, world)
     got = [p.grad.clone() for p in params]
+    # the same through the persistent flat buffer the trainer uses (FlatGradients): .grad are views of ONE tensor, autograd
+    # accumulates into them in place across steps, the exchange is one in-place collective
+    for p in params:
+        p.grad = None
+    fg = D.FlatGradients(params)
+    ptrs = [p.grad.data_ptr() for p in params]
+    for step in range(2):                        # two steps: the views must survive zero + backward
+        fg.zero_()
+        loss_fn(X[rank * 4:(rank + 1) * 4]).backward()
+        assert fg.intact() and [p.grad.data_ptr() for p in params] == ptrs
+        fg.all_reduce_mean_(world)
+    flat_ok = all(torch.allclose(a, p.grad, rtol=1e-6, atol=1e-7) for a, p in zip(got, params))
+    flat_ok = flat_ok and fg.flat.numel() == sum(p.numel() for p in params)
+    params[0].grad = None                        # somebody dropped a grad: re-attached at the next zero_()
+    fg.zero_()
+    flat_ok = flat_ok and fg.intact()
     for p in params:
         p.grad = None
     loss_fn(X).backward()                        # single-process reference on the concatenated batch
     ok = all(torch.allclose(a, p.grad, rtol=1e-5, atol=1e-6) for a, p in zip(got, params))
     mx = D.all_reduce_max(float(rank + 1), torch.device("cpu"))
     D.barrier()
-    ret[rank] = bool(ok and mx == float(world))
+    ret[rank] = bool(ok and flat_ok and mx == float(world))
     dist.destroy_process_group()
 
 

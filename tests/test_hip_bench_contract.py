@@ -38,3 +38,41 @@ def test_bench_line_contract():
     assert j["text_trimmed_to_eot"]["text_positions_evaluated"] < 77 and j["text_trimmed_to_eot"]["value"] > j["value"] * 0.9
     if "clock" in j:
         assert 100.0 < j["clock"]["sclk_mhz_avg"] <= 2500.0 and j["clock"]["samples"] >= 2
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """N > 1 readiness without an N-GPU node: `python bench.py --gpus 2` spawns its own two ranks; with
+    MVLPT_DEBUG_SHARE_GPU=1 both sit on cuda:0 and the collectives go through gloo.  Everything else is the real path: the
+    self-spawn, rendezvous, parameter broadcast, barrier + synchronize timing protocol with max over ranks, the flat gradient
+    all-reduce, and ONE JSON line from rank 0 with the whole-job rate."""
+    env = dict(os.environ, MVLPT_DEBUG_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--batch", "64",
+                          "--no-cpu-baseline", "--no-trim-extra"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["warmup"] == 3 and j["scaling"] == "weak"
+    assert j["config"]["parallelism"] == "dp2" and j["config"]["per_gpu_batch"] == 64 and j["config"]["global_batch"] == 128
+    assert j["config"]["text_tower"] == "replicated per GPU"                       # 100 classes: below the sharding threshold
+    assert abs(j["value"] - 128 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-3      # whole-job rate over BOTH ranks
+    assert j["config"]["loss"] == j["config"]["loss"] and "cpu_baseline" not in j
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_shard_the_text_tower_by_default_for_many_classes():
+    """1000 classes on 2 ranks: the text tower is class-sharded without being asked (bench.py --shard-text default)."""
+    env = dict(os.environ, MVLPT_DEBUG_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "32",
+                          "--classes", "1000", "--no-cpu-baseline", "--no-trim-extra", "--no-kernel-timing"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["text_tower"] == "class-sharded over ranks"

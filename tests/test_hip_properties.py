@@ -304,3 +304,42 @@ def test_cfg4_upt_2191_classes_task_mask_and_soft_labels_batch_256():
         s_after = float(model.cross_entropy(model(x, task=task), soft))
     drop, predicted = s_before - s_after, step * gnorm2
     assert drop > 0 and 0.5 * predicted < drop < 1.5 * predicted, (drop, predicted)
+
+
+def test_cfg5_vitl14_336_upt_1151_classes_batch_128():
+    """BASELINE configs[4], full per-GPU size: ViT-L/14@336 (577 + 4 tokens per image: the streamed pair attention inside a
+    24-layer tower), UPT 4 + 4, the ELEVATER-20 class list (1151 classes, reference tokenizer ids), batch 128.  The oracle
+    cannot run this in test time; what the size cannot hide is checked instead: bitwise determinism, exact 4x linearity in the
+    loss scale (power-of-two scaling commutes with every rounding of the backward), zero gradient for a zero loss, image rows
+    independent of their batch, cross-entropy against torch on the same logits."""
+    arch, model = _model("upt", C=1151, n_ctx=4, n_vpt=4, arch_name="ViT-L/14@336px", class_list="elevater20")
+    B, C = 128, 1151
+    x = _images(arch, B)
+    y = torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(14)).cuda()
+
+    def run(scale=1.0):
+        model.zero_grad(set_to_none=True)
+        logits = model(x)
+        loss = model.cross_entropy(logits, y) * scale
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().clone(), float(loss.detach()), _grads(model)
+
+    l0, s0, g0 = run()
+    assert l0.shape == (B, C) and torch.isfinite(l0).all()
+    assert float(l0.abs().max()) <= math.exp(math.log(1 / 0.07)) * (1 + 1e-5)
+    assert abs(float(torch.nn.functional.cross_entropy(l0, y)) - s0) < 1e-5 * max(1.0, s0)
+    l1, s1, g1 = run()
+    assert torch.equal(l0, l1) and s0 == s1 and all(torch.equal(g0[k], g1[k]) for k in g0), "bitwise deterministic"
+    assert {"ctx", "vpt_embeddings", "vpt_embeddings_deep"} <= set(g0) and g0["vpt_embeddings_deep"].shape == (23, 4, 1024)
+    _, _, g4 = run(4.0)
+    _, _, gz = run(0.0)
+    for k in g0:
+        assert torch.isfinite(g0[k]).all() and float(g0[k].abs().max()) > 0, k
+        assert float((g4[k] - 4.0 * g0[k]).abs().max()) <= 1e-5 * float(g4[k].abs().max()), k
+        assert float(gz[k].abs().max()) == 0.0, k
+    with torch.no_grad():      # inference forwards (single operands): a batch in two halves equals the whole batch bit-exactly
+        full = model(x)
+        halves = torch.cat([model(x[:64].contiguous()), model(x[64:].contiguous())])
+    assert torch.equal(halves, full)
+    assert float((full - l0).abs().max()) <= 1e-3 * float(l0.abs().max()), "training and inference forwards agree to 1e-3"
