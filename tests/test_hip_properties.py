@@ -49,7 +49,10 @@ def _model(method="coop", C=100, n_ctx=16, n_vpt=8, arch_name="ViT-B/16", tasks=
         from mvlpt_amd.class_prompts import load_class_prompts
         pre, n = load_class_prompts(class_list, T.COOP.N_CTX)
         assert n == C
-    model = CustomCLIP(cfg, names, FrozenCLIP(sd, "fp16"), dm=dm, pretokenized=pre).cuda()
+    # synthetic class names get the hash tokenizer (ids independent of the BPE table: the step sizes / tolerances of the tests
+    # below were calibrated on them); BASELINE class lists come pre-tokenised by the reference tokenizer
+    from mvlpt_amd.model import SyntheticTokenizer
+    model = CustomCLIP(cfg, names, FrozenCLIP(sd, "fp16", tokenizer=SyntheticTokenizer()), dm=dm, pretokenized=pre).cuda()
     return arch, model
 
 
