@@ -272,6 +272,9 @@ class LookAheadLoader:
     def __getattr__(self, name):
         return getattr(self.loader, name)
 
+    def __getitem__(self, i):             # list-like loaders (resident synthetic batches)
+        return self.loader[i]
+
     def __iter__(self):
         it = iter(self.loader)
         nxt = next(it, None)
