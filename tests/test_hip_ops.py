@@ -295,3 +295,41 @@ def test_attention32_is_not_transposed():
     out2, _ = E.op_attention32_fwd(qkv.cuda(), N, L, H, False)
     _, _, _, o, _ = _attn_ref(qkv, N, L, H, False)
     assert relerr(E.join_pair(out2), o.reshape(L, 64)) < 5e-6
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(50432, 768, 3072, "resid"),      # MLP down-projection of the headline: 591 tiles of 256x256 -> 79 tiles x 3 parts
+                                       (50432, 3072, 768, "gelu"),       # MLP up-projection: 2364 tiles -> last round of 60 x 4 parts
+                                       (17920, 512, 512, "store32"),     # 128x128 tiles, two workgroups per CU: 560 tiles -> 48 x 4
+                                       (33280, 768, 768, "store16"),     # 256x128 tiles: 780 -> last round of 12 x 4
+                                       (52480, 768, 3072, "resid")])     # 205 row tiles (B = 256 with 8 prompt tokens): 103 x 2
+def test_gemm_streamk_last_round(M, N, K, epi):
+    """Stream-K of the ragged last round (gemm.hip): tiles of that round are cut along K over several workgroups whose fp32
+    partial accumulators are summed in a fixed order by one of them.  Same answer as the plain product, bit-identical from run
+    to run (no atomics, no arrival-order dependence), for every epilogue family and geometry."""
+    E = _eng()
+    dtype = torch.float16
+    g = torch.Generator().manual_seed(M % 1000 + N + K)
+    A = torch.randn(M, K, generator=g).to(dtype).cuda()
+    Bt = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = A.float() @ Bt.float().t() + bias            # on the GPU through torch (fp32 accumulate): 1e-5-level agreement expected
+    kw = dict(bias=bias)
+    if epi == "resid":
+        resid = torch.randn(M, N, generator=g).cuda()
+        run = lambda: E.op_gemm(A, Bt, E._lib.EPI_RESID32, resid=resid, **kw)
+        want, tol = ref + resid, 3e-5
+    elif epi == "gelu":
+        run = lambda: E.op_gemm(A, Bt, E._lib.EPI_GELU, **kw)
+        want, tol = O.quick_gelu(ref.cpu()), TOL[dtype]
+    elif epi == "store32":
+        run = lambda: E.op_gemm(A, Bt, E._lib.EPI_STORE32, **kw)
+        want, tol = ref, 3e-5
+    else:
+        run = lambda: E.op_gemm(A, Bt, E._lib.EPI_STORE16, **kw)
+        want, tol = ref, TOL[dtype]
+    out0 = run()
+    assert relerr(out0, want) < tol
+    # the LAST rows are the ones the split round produces: check them on their own as well
+    assert relerr(out0[-2048:], want[-2048:]) < tol
+    for _ in range(5):
+        assert torch.equal(run(), out0)
