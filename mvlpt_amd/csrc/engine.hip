@@ -76,9 +76,6 @@ struct LNp { float* g = nullptr; float* b = nullptr; };
 struct Block { LNp ln1, ln2; Linear qkv, o, fc, pr; };
 struct TowerW { int width = 0, layers = 0, heads = 0; std::vector<Block> blocks; };
 
-// stream-K workspace of one stream's GEMMs (GemmArgs::sk_ws): the two towers run concurrently, each has its own
-struct SkWs { float* ws = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; };
-
 struct TowerState {
   bool valid = false, saved = false, causal = false;
   bool exact = false;                    // split-precision operands + pair-product attention (see DESIGN.md "Precision modes")
@@ -112,7 +109,6 @@ struct Engine {
   float* tpos = nullptr; LNp ln_final; float *tproj = nullptr, *tproj_t = nullptr;
   std::vector<void*> owned;               // every weight allocation (freed in destroy)
   DevBuf vis_ws, txt_ws, head_ws, ce_ws, tmp, pp_ws;
-  SkWs sk_vis, sk_txt; SkWs* sk_cur = nullptr; bool streamk = true;
   TowerState vs, ts;
   // vision fwd extras (carved from vis_ws)
   int vB = 0, v_nvpt = 0, v_ndeep = 0; float* cls32 = nullptr; float* dcls32 = nullptr;
@@ -163,7 +159,6 @@ hipError_t gemm(Engine* E, int epi, const void* A, WRef Bt, int M, int N, int K,
   GemmArgs g{A, Bt.p, M, N, K, bias, aux, resid, out, out2};
   g.a_split = a_split; g.ldb = Bt.ld; g.w8_exp = Bt.e8;
   g.out_lo8 = (a_split == 2 && (epi == EPI_GELU_SPLIT || epi == EPI_GELUBWD_SPLIT)) ? 1 : 0;
-  if (E && E->sk_cur && E->sk_cur->ws) { g.sk_ws = E->sk_cur->ws; g.sk_flags = E->sk_cur->flags; g.sk_epoch = ++E->sk_cur->epoch; }
   const int dt = dtype >= 0 ? dtype : E->dt;
   const double ob = (epi == EPI_RESID32) ? 8.0 : ((epi == EPI_STORE32 || epi == EPI_STORE_SPLIT) ? 4.0 : ((epi == EPI_GELUBWD || epi == EPI_GELU_SPLIT) ? 4.0 :
                     (epi == EPI_GELUBWD_SPLIT ? 6.0 : 2.0)));
@@ -242,21 +237,6 @@ void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool s
     st.scale_dev = bp.take<float>(4);   // {scale, 1/scale, amax scratch, pad}
   }
   st.valid = true;
-}
-
-// make `w` the stream-K workspace of the GEMMs enqueued from here on (allocated on first use, released with the handle)
-int use_streamk(Engine* E, SkWs& w, hipStream_t s) {
-  E->sk_cur = nullptr;
-  if (!E->streamk) return 0;
-  if (!w.ws) {
-    void *a = nullptr, *f = nullptr;
-    HIPCHK(E, hipMalloc(&a, GEMM_SK_WS_BYTES)); E->owned.push_back(a);
-    HIPCHK(E, hipMalloc(&f, GEMM_SK_FLAG_BYTES)); E->owned.push_back(f);
-    HIPCHK(E, hipMemsetAsync(f, 0, GEMM_SK_FLAG_BYTES, s));
-    w.ws = (float*)a; w.flags = (unsigned*)f; w.epoch = 0;
-  }
-  E->sk_cur = &w;
-  return 0;
 }
 
 // which pair format a split tower uses: the default mode carries the residual as one e5m2 byte (GemmArgs::a_split == 2);
@@ -465,7 +445,6 @@ int mvlpt_create(const MvlptArch* a, void** handle) {
   Engine* E = new Engine();
   E->arch = *a; E->dt = a->compute_dtype;
   if (const char* v = getenv("MVLPT_SPLIT_LO8")) E->lo8 = atoi(v) != 0;
-  if (const char* v = getenv("MVLPT_GEMM_STREAMK")) E->streamk = atoi(v) != 0;
   E->vis.width = a->vision_width; E->vis.layers = a->vision_layers; E->vis.heads = a->vision_heads;
   E->vis.blocks.resize(a->vision_layers);
   E->txt.width = a->text_width; E->txt.layers = a->text_layers; E->txt.heads = a->text_heads;
@@ -582,7 +561,6 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   if ((n_vpt > 0) != (vpt != nullptr)) return fail(E, MVLPT_ERR_ARG, "image_fwd: vpt pointer and n_vpt disagree");
   if ((n_deep > 0) != (vpt_deep != nullptr) || (n_deep > 0 && n_vpt <= 0)) return fail(E, MVLPT_ERR_ARG, "image_fwd: deep prompts need vpt");
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = use_streamk(E, E->sk_vis, s)) return rc;
   const MvlptArch& A = E->arch;
   const int G = A.image_resolution / A.patch_size, G2 = G * G, dv = A.vision_width, e = A.embed_dim;
   const int Lv = 1 + n_vpt + G2;
@@ -683,7 +661,6 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
   if (!st.valid || !st.saved) return fail(E, MVLPT_ERR_STATE, "image_bwd: call image_fwd(save_for_bwd=1) first");
   if ((E->v_nvpt > 0 && !dvpt) || (E->v_ndeep > 0 && !dvpt_deep)) return fail(E, MVLPT_ERR_ARG, "image_bwd: missing gradient output");
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = use_streamk(E, E->sk_vis, s)) return rc;
   const MvlptArch& A = E->arch;
   const int B = E->vB, dv = A.vision_width, e = A.embed_dim, Lv = st.L, n = E->v_nvpt;
   const size_t T = (size_t)B * Lv;
@@ -759,7 +736,6 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
   if (L > A.context_length) return fail(E, MVLPT_ERR_ARG, "text_fwd: L exceeds context_length");
   if (L > attn_max_len()) return fail(E, MVLPT_ERR_UNSUPPORTED, "text_fwd: L > 256");
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = use_streamk(E, E->sk_txt, s)) return rc;
   const int dtw = A.text_width, e = A.embed_dim;
   const bool save = save_for_bwd != 0;
   // n_ctx == 0: the text features are constants of the run (computed once and cached by the caller) that
@@ -830,7 +806,6 @@ int mvlpt_text_bwd(void* h, const float* dfeat, float* dctx, mvlpt_stream_t stre
   if (!st.valid || !st.saved) return fail(E, MVLPT_ERR_STATE, "text_bwd: call text_fwd(save_for_bwd=1) first");
   if (E->t_nctx <= 0) return fail(E, MVLPT_ERR_STATE, "text_bwd: the forward had no context tokens");
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = use_streamk(E, E->sk_txt, s)) return rc;
   const MvlptArch& A = E->arch;
   const int C = E->tC, L = E->tL, dtw = A.text_width, e = A.embed_dim;
   const size_t T = (size_t)C * L;
@@ -929,26 +904,9 @@ int mvlpt_cross_entropy(void* h, const float* logits, const void* labels, int ki
 // ------------------------------------------------------------------------------------------------ kernel-level ops
 #define OPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(_e); return MVLPT_ERR_HIP; } } while (0)
 
-// the kernel-level GEMM entry points share one stream-K workspace (single-stream callers: the parity tests)
-static int op_streamk(GemmArgs& g, hipStream_t s) {
-  static SkWs w;
-  static const bool on = !(getenv("MVLPT_GEMM_STREAMK") && atoi(getenv("MVLPT_GEMM_STREAMK")) == 0);
-  if (!on) return 0;
-  if (!w.ws) {
-    void *a = nullptr, *f = nullptr;
-    OPCHK(hipMalloc(&a, GEMM_SK_WS_BYTES));
-    OPCHK(hipMalloc(&f, GEMM_SK_FLAG_BYTES));
-    OPCHK(hipMemsetAsync(f, 0, GEMM_SK_FLAG_BYTES, s));
-    w.ws = (float*)a; w.flags = (unsigned*)f;
-  }
-  g.sk_ws = w.ws; g.sk_flags = w.flags; g.sk_epoch = ++w.epoch;
-  return 0;
-}
-
 int mvlpt_op_gemm(int dtype, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
                   const float* resid, void* out, void* out2, mvlpt_stream_t stream) {
   GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
-  if (int rc = op_streamk(g, (hipStream_t)stream)) return rc;
 #ifdef MVLPT_GEMM_TRACE
   // debug builds: timeline of workgroup 0 -> $MVLPT_GEMM_TRACE_FILE (8 waves x 2048 int64 records)
   const char* path = getenv("MVLPT_GEMM_TRACE_FILE");
@@ -972,7 +930,6 @@ int mvlpt_op_gemm_split(int dtype, int epi, const void* A, const void* Bt, int M
                         const float* resid, void* out, void* out2, mvlpt_stream_t stream) {
   GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
   g.a_split = 1;
-  if (int rc = op_streamk(g, (hipStream_t)stream)) return rc;
   OPCHK(launch_gemm(dtype, epi, g, (hipStream_t)stream));
   return 0;
 }
@@ -1001,7 +958,6 @@ int mvlpt_op_gemm_mixed(int dtype, int epi, const void* A, const void* Bt, int l
   GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
   g.a_split = 2; g.ldb = ldb; g.w8_exp = w8_exp;
   g.out_lo8 = (epi == EPI_GELU_SPLIT || epi == EPI_GELUBWD_SPLIT) ? 1 : 0;
-  if (int rc = op_streamk(g, (hipStream_t)stream)) return rc;
   OPCHK(launch_gemm(dtype, epi, g, (hipStream_t)stream));
   return 0;
 }

@@ -184,12 +184,6 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
   }
 }
 
-// K-stages of one tile: K/64 16-bit stages; a 16-bit pair doubles them, a mixed pair adds K/128 fp8 stages
-__device__ __forceinline__ int nk_total(const GemmArgs& g) {
-  const int nkb = g.K / BK;
-  return g.a_split == 2 ? nkb + nkb / 2 : (g.a_split ? 2 * nkb : nkb);
-}
-
 // BM_ x 128 tile, NW waves arranged (NW/2) x 2, NS-deep LDS ring.  Persistent: gridDim.x resident workgroups walk
 // the tile list in rounds and keep the LDS-DMA pipeline running ACROSS tile boundaries (the first K-stages of the
 // next tile are in flight while the current tile finishes and its epilogue is stored), so the short-K GEMMs of
@@ -226,28 +220,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   // Tile enumeration: N-fastest (the tiles an XCD runs concurrently share 1-2 A panels).  A grouped, weight-resident
   // enumeration was measured and was not faster (A panels are then re-read from the Infinity Cache once per group).
   auto tile_mn = [&](int t, int& tm, int& tn) { tm = t / tilesN; tn = t - tm * tilesN; };
-  // Work items.  Rounds of G tiles with all of K each; the ragged LAST round (rem = ntiles mod G tiles) is cut along K when it
-  // would leave most of the chip idle (stream-K, deterministic): S = min(G / rem, 4) workgroups share a tile, each runs a
-  // contiguous range of its K-stages, parts 1..S-1 hand their fp32 accumulators to part 0 through g.sk_ws, part 0 adds them in
-  // a fixed order and runs the epilogue.  E.g. M = 50432, N = 768, K = 3072 (MLP down-projection, 591 tiles of 256x256 on 256
-  // CUs): 2 + 1/3 rounds of matrix time instead of 3.
-  const int full_rounds = ntiles / G, rem = ntiles - full_rounds * G;
-  int S = 1;
-  if (g.sk_ws && full_rounds >= 1 && rem > 0 && 2 * rem <= G && rem <= GEMM_SK_SLOTS) {
-    S = G / rem; S = S > 4 ? 4 : S;
-    while (S > 1 && nk_total(g) / S < 4) --S;
-  }
-  auto item_of = [&](int round, int& tile, int& ka, int& kb) -> bool {
-    const int nkt = nk_total(g);
-    ka = 0; kb = nkt;
-    if (round < full_rounds) { tile = round * G + b_remap; return true; }
-    if (round > full_rounds) return false;
-    if (S == 1) { tile = round * G + b; return b < rem; }       // ragged last round: plain order keeps XCDs balanced
-    if (b >= rem * S) return false;
-    const int part = b / rem;
-    tile = round * G + (b - part * rem);
-    ka = part * nkt / S; kb = (part + 1) * nkt / S;
-    return true;
+  auto tile_of = [&](int round) -> int {
+    const int base = round * G;
+    return base + ((base + G <= ntiles) ? b_remap : b);   // ragged last round: plain order keeps XCDs balanced
   };
 
   // ---- staging: thread -> (row, 16B chunk) of a 1 KiB LDS slab (8 rows x 128 B); the LDS image is lane-linear,
@@ -277,12 +252,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   // k-values); the fp8 planes follow the 16-bit ones in the A and Bt rows, so stage f sits at element offset f*BK of both.
   const bool mixed = g.a_split == 2;
   const int nkb = K / BK, nk = mixed ? nkb + nkb / 2 : (g.a_split ? 2 * nkb : nkb);
-  int lround = 0, lt = 0, lkt = 0, lk1 = 0, lslot = 0;
-  bool lmore = item_of(0, lt, lkt, lk1);
-  if (!lmore) return;
+  int lround = 0, lt = tile_of(0), lkt = 0, lslot = 0;
+  if (lt >= ntiles) return;
   set_ptrs(lt);
   auto issue = [&]() -> bool {
-    if (!lmore) return false;
+    if (lt >= ntiles) return false;
     char* base = smem + lslot * STAGE;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) glds16(ap[i] + lkt * BK, base + (i * NW + wave) * 1024);
@@ -290,9 +264,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) glds16(bp[i] + bk, base + A_BYTES + (i * NW + wave) * 1024);
     lslot = lslot + 1 == NS ? 0 : lslot + 1;
-    if (++lkt == lk1) {
-      lmore = item_of(++lround, lt, lkt, lk1);
-      if (lmore) set_ptrs(lt);
+    if (++lkt == nk) {
+      lkt = 0;
+      lt = tile_of(++lround);
+      if (lt < ntiles) set_ptrs(lt);
     }
     return true;
   };
@@ -327,9 +302,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
 
   bool stores_pending = false;
   int slot = 0;
-  for (int round = 0;; ++round) {
-    int t, kt0, kt1;
-    if (!item_of(round, t, kt0, kt1)) break;
+  int t = tile_of(0);
+  for (int round = 0; t < ntiles; t = tile_of(++round)) {
     f32x4 acc[WMF / 4][4][4];
 #pragma unroll
     for (int i = 0; i < WMF; ++i)
@@ -373,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
       slot = slot + 1 == NS ? 0 : slot + 1;
         };
     const int nk16 = mixed ? nkb : nk;
-    for (int kt = kt0; kt < (kt1 < nk16 ? kt1 : nk16); ++kt) {
+    for (int kt = 0; kt < nk16; ++kt) {
       stage_pre();
       const char* base = smem + slot * STAGE;
       // Register-buffered fragment pipeline: the ds_reads of MFMA group s+1 (two A fragments, plus the four B fragments
@@ -426,7 +400,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
       }
       stage_post();
     }
-    for (int kt = (kt0 > nk16 ? kt0 : nk16); kt < kt1; ++kt) {
+    for (int kt = nk16; kt < nk; ++kt) {
       stage_pre();
       const char* base = smem + slot * STAGE;
         // fp8 stage of the mixed pair: ONE k-step of 128 on v_mfma_scale_f32_16x16x128_f8f6f4 (32 cycles per instruction:
@@ -458,33 +432,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
       stage_post();
     }
     MVLPT_TR(8);
-    if (S > 1 && round == full_rounds) {
-      // stream-K hand-off (last round: nothing of this workgroup is in flight any more).  Fragment-linear fp32 images: lane l
-      // of wave w keeps accumulator a at float4 slot (w * NACC + a) * 64 + l — 1 KiB per wave instruction, both ways.
-      constexpr int NACC = WMF * 4;
-      const int part = b / rem, tslot = t - full_rounds * G;
-      f32x4* img = (f32x4*)g.sk_ws + ((size_t)tslot * 3) * (size_t)(BM_ * BN / 4) + (size_t)(wave * NACC) * 64 + lane;
-      unsigned* flags = g.sk_flags + tslot * 4;
-      if (part > 0) {
-        f32x4* dst = img + (size_t)(part - 1) * (BM_ * BN / 4);
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) dst[a * 64] = acc[a >> 4][(a >> 2) & 3][a & 3];
-        __threadfence();                                   // release (agent scope): own stores visible before the flag
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(flags + part, g.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      for (int p = 1; p < S; ++p) {                        // fixed order: the sum does not depend on arrival order
-        if (tid == 0) {
-          while (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.sk_epoch) __builtin_amdgcn_s_sleep(8);
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const f32x4* src = img + (size_t)(p - 1) * (BM_ * BN / 4);
-#pragma unroll
-        for (int a = 0; a < NACC; ++a) acc[a >> 4][(a >> 2) & 3][a & 3] += src[a * 64];
-      }
-    }
     // the slot the load cursor will fill next has just been released by the barrier above: use it as scratch,
     // and fence the scratch reads of all waves against that DMA with one more barrier
     int tm, tn;

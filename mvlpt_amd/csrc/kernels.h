@@ -41,12 +41,6 @@ struct GemmArgs {
   int ldb = 0;         // Bt row pitch in 16-bit elements (0: K)
   int w8_exp = 0;      // a_split == 2: exponent of the weight's fp8 plane
   int out_lo8 = 0;     // EPI_GELU_SPLIT / EPI_GELUBWD_SPLIT: store the pair as [hi | lo8] (mixed pair) instead of [hi | lo]
-  // Stream-K of the ragged last round (gemm.hip): workspace for the fp32 partial accumulators (GEMM_SK_SLOTS tiles x 3
-  // parts x 256x256 floats), one flag word per (tile slot, part), and the launch's epoch (flags are compared for equality with
-  // it and never reset).  One workspace per stream: launches that may run concurrently must not share it.  null: off.
-  float* sk_ws = nullptr;
-  unsigned* sk_flags = nullptr;
-  unsigned sk_epoch = 0;
 #ifdef MVLPT_GEMM_TRACE
   long long* trace = nullptr;   // debug builds only: per-wave (point id << 56 | s_memtime) records of workgroup 0
 #endif
@@ -55,9 +49,6 @@ struct GemmArgs {
 // extra marker packets on the stream.
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hipEvent_t ev_start = nullptr,
                        hipEvent_t ev_stop = nullptr);
-constexpr int GEMM_SK_SLOTS = 128;                                                  // tiles of a split last round (<= half the CUs)
-constexpr size_t GEMM_SK_WS_BYTES = (size_t)GEMM_SK_SLOTS * 3 * 256 * 256 * 4;      // partial accumulators
-constexpr size_t GEMM_SK_FLAG_BYTES = (size_t)GEMM_SK_SLOTS * 4 * 4;
 
 // fp32 GEMM on the f32-input MFMA (exact f32 products, v_mfma_f32_16x16x4_f32) for the two tiny projections
 // next to the logits (CLS / EOT rows only): C[M,N] = alpha * A[M,K] * Bt[N,K]^T.  K % 16 == 0, N % 4 == 0.

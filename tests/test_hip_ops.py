@@ -297,15 +297,15 @@ def test_attention32_is_not_transposed():
     assert relerr(E.join_pair(out2), o.reshape(L, 64)) < 5e-6
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(50432, 768, 3072, "resid"),      # MLP down-projection of the headline: 591 tiles of 256x256 -> 79 tiles x 3 parts
-                                       (50432, 3072, 768, "gelu"),       # MLP up-projection: 2364 tiles -> last round of 60 x 4 parts
-                                       (17920, 512, 512, "store32"),     # 128x128 tiles, two workgroups per CU: 560 tiles -> 48 x 4
-                                       (33280, 768, 768, "store16"),     # 256x128 tiles: 780 -> last round of 12 x 4
-                                       (52480, 768, 3072, "resid")])     # 205 row tiles (B = 256 with 8 prompt tokens): 103 x 2
-def test_gemm_streamk_last_round(M, N, K, epi):
-    """Stream-K of the ragged last round (gemm.hip): tiles of that round are cut along K over several workgroups whose fp32
-    partial accumulators are summed in a fixed order by one of them.  Same answer as the plain product, bit-identical from run
-    to run (no atomics, no arrival-order dependence), for every epilogue family and geometry."""
+@pytest.mark.parametrize("M,N,K,epi", [(50432, 768, 3072, "resid"),      # MLP down-projection of the headline: 591 tiles of 256x256
+                                       (50432, 3072, 768, "gelu"),       # MLP up-projection: 2364 tiles
+                                       (17920, 512, 512, "store32"),     # 128x128 tiles, two workgroups per CU: 560 tiles
+                                       (33280, 768, 768, "store16"),     # 256x128 tiles: 780
+                                       (52480, 768, 3072, "resid")])     # 205 row tiles (B = 256 with 8 prompt tokens)
+def test_gemm_ragged_last_round_full_size(M, N, K, epi):
+    """Full-size GEMMs of the BASELINE configurations whose persistent grid ends in a ragged round (591 / 2364 / 560 / 780 / 615
+    tiles on 256 CUs), every epilogue family and geometry: right answer, bit-identical from run to run.  (Round 3 also built a
+    deterministic stream-K split of that last round — commit 8445596 — and measured it neutral: DESIGN.md §5.)"""
     E = _eng()
     dtype = torch.float16
     g = torch.Generator().manual_seed(M % 1000 + N + K)
