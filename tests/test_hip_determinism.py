@@ -87,3 +87,50 @@ def test_image_tower_with_backward_is_bit_stable_under_a_concurrent_text_tower(i
             torch.cuda.synchronize()
             assert torch.equal(f, f0), f"image features changed under a concurrent text tower (iteration {it})"
             assert torch.equal(a, a0) and torch.equal(b, b0), f"visual-prompt gradients changed under a concurrent text tower (iteration {it})"
+
+
+@pytest.mark.parametrize("method", ["vpt", "upt"])
+def test_full_step_at_batch_256_is_bit_stable_with_both_towers_concurrent(method):
+    """The whole training step of the configurations that carry an image backward, at the BASELINE batch of 256: image tower
+    (split operands, forward + backward) and — UPT — the text tower forward + backward on the second stream, as CustomCLIP.forward
+    schedules them.  Logits, loss and every prompt gradient must be bit-identical across repetitions, with a third stream
+    hammering the chip at varying phase (the scheduling of the towers against each other changes from repetition to repetition)."""
+    from mvlpt_amd.class_prompts import load_class_prompts
+    from mvlpt_amd.config import get_cfg_default
+    from mvlpt_amd.model import CustomCLIP, FrozenCLIP
+    from mvlpt_amd.weights import ARCHS, make_state_dict
+    arch = ARCHS["ViT-B/16"]
+    cfg = get_cfg_default()
+    T = cfg.TRAINER.MVLPT
+    T.COOP.N_CTX = 4 if method == "upt" else 0
+    T.VPT.N_CTX, T.VPT.DEEP = 4 if method == "upt" else 8, True
+    T.PROJECT_DIM = 128 if method == "upt" else -1
+    T.PROJECT_METHOD = "transformer" if method == "upt" else "identity"
+    pre, C = load_class_prompts("caltech101", T.COOP.N_CTX)
+    torch.manual_seed(0)
+    model = CustomCLIP(cfg, ["c"] * C, FrozenCLIP(make_state_dict(arch, 3), "fp16"), pretokenized=pre).cuda()
+    assert model.overlap_towers
+    B = 256
+    x = torch.randn(B, 3, 224, 224, device="cuda").half()
+    y = torch.randint(0, C, (B,), device="cuda")
+    noise = torch.randn(64 << 20, device="cuda")
+    third = torch.cuda.Stream()
+
+    def step(k):
+        model.zero_grad(set_to_none=True)
+        with torch.cuda.stream(third):                      # unrelated traffic, a different amount every repetition
+            for _ in range(k % 5):
+                noise.mul_(1.0001)
+        logits = model(x)
+        loss = model.cross_entropy(logits, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().clone(), loss.detach().clone(), {n: p.grad.clone() for n, p in model.prompt_learner.named_parameters() if p.grad is not None}
+
+    l0, s0, g0 = step(0)
+    assert len(g0) >= 2 and all(torch.isfinite(v).all() for v in g0.values())
+    for k in range(1, 9):
+        l, s, g = step(k)
+        assert torch.equal(l, l0) and torch.equal(s, s0), f"logits / loss changed (repetition {k})"
+        for n in g0:
+            assert torch.equal(g[n], g0[n]), f"{n} changed (repetition {k})"
