@@ -405,9 +405,13 @@ def main():
             sustained = MFMA_PEAK_TFLOPS * clock["sclk_mhz_avg"] / _ClockSampler.NOMINAL_MHZ
             line["step_mfma_fraction_at_measured_clock"] = round(ips / world * gf_img / (sustained * 1e3), 4)
         traffic = None
-        if os.path.isfile(TRAFFIC_FILE) and is_headline:
-            with open(TRAFFIC_FILE) as f:
-                traffic = json.load(f)       # {"bytes_per_launch": …, "source": "rocprofv3 --pmc …"} (offline PMC passes)
+        # offline PMC passes (tools/r03_profile.sh): the headline's file, and one per BASELINE config that carries an image backward
+        cfg_key = {("vpt", "ViT-B/16", 1000): "cfg3", ("upt", "ViT-B/16", 2191): "cfg4", ("upt", "ViT-L/14@336px", 1151): "cfg5"}.get(
+            (args.method, args.arch, args.classes))
+        tfile = TRAFFIC_FILE if is_headline else (TRAFFIC_FILE.replace(".json", f"_{cfg_key}.json") if cfg_key and not args.cut else None)
+        if tfile and os.path.isfile(tfile):
+            with open(tfile) as f:
+                traffic = json.load(f)       # {"bytes_per_launch": …, "source": "rocprofv3 --pmc …"}
         n_sampled = len(range(0, K, sample_every))
         if "gemm_bt" in stats:
             g = stats["gemm_bt"]

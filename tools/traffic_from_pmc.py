@@ -2,7 +2,7 @@
 MI355X_MICROARCH.md §HBM prescribes: on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads
 (all reads of this kernel are 16 B/lane) -> doubled; WRITE_SIZE is taken as is (it matches the known output sizes of
 the LayerNorm / residual-GEMM launches exactly).  Units of the raw counters: KB.
-Usage: python tools/traffic_from_pmc.py <fetch.db> <write.db> > profiles/gemm_hbm_traffic.json"""
+Usage: python tools/traffic_from_pmc.py <fetch.db> <write.db> [label] > profiles/gemm_hbm_traffic.json"""
 import json, re, sqlite3, sys
 
 def per_kernel(dbp, counter):
@@ -16,7 +16,8 @@ rd, wr = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_S
 g = [k for k in rd if "gemm_bt_kernel" in k or "gemm_bt_phased_kernel" in k]
 n = sum(rd[k][0] for k in g); fr = sum(rd[k][1] for k in g)
 nw = sum(wr[k][0] for k in g if k in wr); fw = sum(wr[k][1] for k in g if k in wr)
-out = {"kernel": "gemm_bt_kernel + gemm_bt_phased_kernel (all epilogues/geometries, headline bench step)", "launches_sampled": n,
+what = sys.argv[3] if len(sys.argv) > 3 else "headline bench step"
+out = {"kernel": f"gemm_bt_kernel + gemm_bt_phased_kernel (all epilogues/geometries, {what})", "launches_sampled": n,
        "FETCH_SIZE_kb_avg_raw": round(fr / n, 1), "WRITE_SIZE_kb_avg_raw": round(fw / nw, 1),
        "bytes_per_launch": int((2.0 * fr / n + fw / nw) * 1024),
        "correction": "2 x FETCH_SIZE (gfx950 half-count of 16 B/lane reads) + WRITE_SIZE; counters in KB; includes Infinity-Cache hits",
