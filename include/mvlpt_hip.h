@@ -53,6 +53,10 @@ enum { MVLPT_PREC_FAST = 0, MVLPT_PREC_SPLIT_GRAD = 1, MVLPT_PREC_SPLIT_ALL = 2 
 int mvlpt_create(const MvlptArch* arch, void** handle);
 /* switch the precision mode (takes effect at the next tower forward) */
 int mvlpt_set_precision(void* handle, int mode);
+/* Workspaces only grow, and a block that was outgrown is retired (not freed) so that no step ever meets a device-wide sync.
+ * mvlpt_trim synchronises the device and releases the retired blocks: call it at an epoch boundary (e.g. after a one-off large
+ * evaluation batch or class list). */
+int mvlpt_trim(void* handle);
 int mvlpt_destroy(void* handle);
 const char* mvlpt_last_error(void* handle); /* handle may be NULL for create() failures */
 const char* mvlpt_version(void);
@@ -110,7 +114,9 @@ int mvlpt_cross_entropy(void* handle, const float* logits, const void* labels, i
 int mvlpt_op_gemm(int dtype, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
                   const float* resid, void* out, void* out2, mvlpt_stream_t stream);
 /* same with a split-precision A operand: A is [M, 2K] = [A_hi | A_lo] (16-bit pair), C = (A_hi + A_lo) * Bt^T; additional
- * epilogues 5 (out [M,2N] = hi|lo pair of QuickGELU(acc+bias), out2 = pre-activation) and 6 (pair of acc*QuickGELU'(aux)) */
+ * epilogues 5 (out [M,2N] = hi|lo pair of QuickGELU(acc+bias), out2 = pre-activation) and 6 (pair of acc*QuickGELU'(aux)).
+ * Note: the saved pre-activation `out2` is ONE 16-bit value per element in every mode (QuickGELU' is evaluated on it in the
+ * backward): the one operand of the split towers that is not a pair; the parity budget carries it (gradients 1-7e-4 of 1e-3). */
 int mvlpt_op_gemm_split(int dtype, int epi, const void* A, const void* Bt, int M, int N, int K, const float* bias, const void* aux,
                         const float* resid, void* out, void* out2, mvlpt_stream_t stream);
 /* LayerNorm with the 16-bit output written as a hi|lo pair [rows, 2d] */

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mvlpt_create": (_i, [C.POINTER(MvlptArch), C.POINTER(_vp)]),
     "mvlpt_destroy": (_i, [_vp]),
     "mvlpt_set_precision": (_i, [_vp, _i]),
+    "mvlpt_trim": (_i, [_vp]),
     "mvlpt_last_error": (C.c_char_p, [_vp]),
     "mvlpt_version": (C.c_char_p, []),
     "mvlpt_load_frozen": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i, _vp]),

@@ -41,6 +41,13 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     for (void* q : retired) (void)hipFree(q);
   }
+  // release the retired blocks; the caller guarantees that nothing enqueued before still uses them (mvlpt_trim)
+  size_t trim() {
+    size_t n = retired.size();
+    for (void* q : retired) (void)hipFree(q);
+    retired.clear();
+    return n;
+  }
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
     size_t got = std::max(bytes, cap + cap / 2);
@@ -461,6 +468,14 @@ int mvlpt_set_precision(void* h, int mode) {
   if (mode != MVLPT_PREC_FAST && mode != MVLPT_PREC_SPLIT_GRAD && mode != MVLPT_PREC_SPLIT_ALL)
     return fail(E, MVLPT_ERR_ARG, "set_precision: unknown mode");
   E->prec_mode = mode;
+  return 0;
+}
+
+int mvlpt_trim(void* h) {
+  Engine* E = (Engine*)h;
+  if (!E) return MVLPT_ERR_ARG;
+  HIPCHK(E, hipDeviceSynchronize());       // epoch boundary: a host-side pause is acceptable here, never inside a step
+  for (DevBuf* b : {&E->vis_ws, &E->txt_ws, &E->head_ws, &E->ce_ws, &E->tmp, &E->pp_ws}) (void)b->trim();
   return 0;
 }
 

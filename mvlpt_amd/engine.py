@@ -90,6 +90,10 @@ class Engine:
         _lib.check(lib.mvlpt_set_precision(self.h, int(code)), self.h, "set_precision")
         self.precision = int(code)
 
+    def trim(self) -> None:
+        """Release workspace blocks that were outgrown (epoch boundary: synchronises the device)."""
+        _lib.check(lib.mvlpt_trim(self.h), self.h, "trim")
+
     @classmethod
     def from_state_dict(cls, sd: Dict[str, torch.Tensor], compute_dtype: str = "fp16", device=None,
                         arch: Optional[ClipArch] = None) -> "Engine":

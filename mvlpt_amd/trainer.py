@@ -208,6 +208,7 @@ class TrainerX:
     def train(self):
         for self.epoch in range(self.start_epoch, self.max_epoch):
             self.run_epoch()
+            self.after_epoch()
             if self.epoch + 1 == self.max_epoch:
                 self.save_model(self.epoch, self.output_dir)
 
@@ -236,6 +237,9 @@ class TrainerX:
         finally:
             self.end_of_epoch_loop()
         return summary
+
+    def after_epoch(self):
+        """Epoch boundary hook (Dassl's after_epoch): concrete trainers release what only a step needed."""
 
     def end_of_epoch_loop(self):
         """The loop left the loader (exhausted, hook break, exception): nothing of the look-ahead may survive it."""
@@ -444,6 +448,9 @@ class MVLPT(TrainerX):
         self._parsed_ahead = None
         if getattr(self, "model", None) is not None:
             self.model.drop_prefetch()
+
+    def after_epoch(self):
+        self.model.engine.trim()          # workspace blocks outgrown during the epoch (a larger eval batch, more classes)
 
     def parse_batch_train(self, batch):
         if self.cfg.DATASET.COOP:

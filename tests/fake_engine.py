@@ -9,6 +9,9 @@ from mvlpt_amd.weights import _randn
 
 
 class OracleEngine:
+    def trim(self):
+        pass
+
     def __init__(self, sd, arch):
         self.sd, self.arch = sd, arch
 

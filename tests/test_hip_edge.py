@@ -103,3 +103,21 @@ def test_loud_failures():
     cfg.TRAINER.MVLPT.COCOOP.N_CTX = 4
     with pytest.raises(NotImplementedError):
         CustomCLIP(cfg, ["dog"], FrozenCLIP(sd, "fp16"))        # CoCoOp is out of scope: refused, not emulated
+
+
+def test_trim_releases_outgrown_workspaces_and_the_engine_keeps_working():
+    """mvlpt_trim: workspaces only grow and retire what they outgrow; trim frees the retired blocks at an epoch
+    boundary.  The engine must give the same answers before and after."""
+    from mvlpt_amd.model import FrozenCLIP
+    from mvlpt_amd.weights import ARCHS, make_state_dict
+    arch = ARCHS["tiny"]
+    eng = FrozenCLIP(make_state_dict(arch, seed=5)).engine
+    g = torch.Generator().manual_seed(0)
+    small = torch.randn(2, 3, arch.image_resolution, arch.image_resolution, generator=g).cuda()
+    big = torch.randn(64, 3, arch.image_resolution, arch.image_resolution, generator=g).cuda()
+    f_small = eng.image_fwd(small).clone()
+    f_big = eng.image_fwd(big).clone()                       # the workspace grows: the small block is retired, not freed
+    eng.trim()
+    assert torch.equal(eng.image_fwd(small), f_small) and torch.equal(eng.image_fwd(big), f_big)
+    eng.trim()                                                # nothing retired: a no-op
+    assert torch.equal(eng.image_fwd(small), f_small)
