@@ -188,7 +188,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
 // the tile list in rounds and keep the LDS-DMA pipeline running ACROSS tile boundaries (the first K-stages of the
 // next tile are in flight while the current tile finishes and its epilogue is stored), so the short-K GEMMs of
 // this path (K = 768 / 512) do not pay a load bubble per tile.
-template <typename T, int EPI, int BM_, int BN_, int NW, int NS>
+template <typename T, int EPI, int BM_, int BN_, int NW, int NS, bool MIXED>
 __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2) void gemm_bt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using v8 = typename Vec<T>::v8;
@@ -250,7 +250,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   // split-precision A ([M,2K] = [hi | lo], kernels.h): 2K/BK stages, the Bt K-index wraps after K/BK of them.
   // Mixed pair (a_split == 2): K/BK 16-bit stages, then K/128 fp8 stages of the same byte size (128-byte rows = 128
   // k-values); the fp8 planes follow the 16-bit ones in the A and Bt rows, so stage f sits at element offset f*BK of both.
-  const bool mixed = g.a_split == 2;
+  // (MIXED is a template parameter: with the fp8 loop compiled into every instantiation the single-operand kernels carry
+  // ~17 more VGPRs and the 256x256 residual epilogue spills: K = 3072, N = 768 went 267 -> 290 us)
+  constexpr bool mixed = MIXED;
   const int nkb = K / BK, nk = mixed ? nkb + nkb / 2 : (g.a_split ? 2 * nkb : nkb);
   int lround = 0, lt = tile_of(0), lkt = 0, lslot = 0;
   if (lt >= ntiles) return;
@@ -280,8 +282,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   const int c0 = ((0 + fg) ^ (fr & 7)) * 16;        // k-step 0 chunk
   const int c1 = ((4 + fg) ^ (fr & 7)) * 16;        // k-step 1 chunk
   // fp8 stage: the lane's 32 consecutive k-bytes (k = 32 fg .. 32 fg + 31) are source chunks 2 fg and 2 fg + 1
-  const int e0 = ((2 * fg) ^ (fr & 7)) * 16, e1 = ((2 * fg + 1) ^ (fr & 7)) * 16;
-  const int sc_w = 127 - g.w8_exp, sc_a = 127 - Lo8<T>::EXP;      // e8m0 scale bytes: undo the exponents of the two fp8 planes
+  [[maybe_unused]] const int e0 = ((2 * fg) ^ (fr & 7)) * 16, e1 = ((2 * fg + 1) ^ (fr & 7)) * 16;
+  [[maybe_unused]] const int sc_w = 127 - g.w8_exp, sc_a = 127 - Lo8<T>::EXP;      // e8m0 scale bytes: undo the exponents of the two fp8 planes
 
   // prologue: fill NS-1 ring slots, wait for the first.  `n_issued` K-stages have been requested so far; a wait that
   // must guarantee stage j may leave the n_issued - (j + 1) younger stages in flight (vmcnt retires in order).
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
       }
       stage_post();
     }
+    if constexpr (MIXED)
     for (int kt = nk16; kt < nk; ++kt) {
       stage_pre();
       const char* base = smem + slot * STAGE;
@@ -617,12 +620,12 @@ static hipError_t launch_phased(const GemmArgs& g, hipStream_t s, hipEvent_t ea,
   return hipGetLastError();
 }
 
-template <typename T, int EPI, int BM_, int BN_, int NW, int NS>
-static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+template <typename T, int EPI, int BM_, int BN_, int NW, int NS, bool MIXED>
+static hipError_t launch_geo_m(const GemmArgs& g, int wg_per_cu, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
   constexpr int LDS = NS * (BM_ + BN_) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   static int cus = 0;
@@ -636,9 +639,17 @@ static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hi
   }
   const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
   const int resident = cus * wg_per_cu;
-  hipExtLaunchKernelGGL((gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), LDS, s,
+  hipExtLaunchKernelGGL((gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), LDS, s,
                         ea, eb, 0, g);
   return hipGetLastError();
+}
+template <typename T, int EPI, int BM_, int BN_, int NW, int NS>
+static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  // the mixed pair only exists with the epilogues a split tower uses (fp32 outputs and the pair-producing ones)
+  if constexpr (EPI == EPI_RESID32 || EPI == EPI_STORE32 || EPI == EPI_GELU_SPLIT || EPI == EPI_GELUBWD_SPLIT || EPI == EPI_STORE_SPLIT) {
+    if (g.a_split == 2) return launch_geo_m<T, EPI, BM_, BN_, NW, NS, true>(g, wg_per_cu, s, ea, eb);
+  } else if (g.a_split == 2) return hipErrorInvalidValue;
+  return launch_geo_m<T, EPI, BM_, BN_, NW, NS, false>(g, wg_per_cu, s, ea, eb);
 }
 
 static int num_cus() {
