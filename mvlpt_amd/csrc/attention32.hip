@@ -26,6 +26,15 @@
 
 namespace mvlpt {
 
+// Debug timeline of one workgroup of the streamed forward (tools/attn_trace.py; builds with -DMVLPT_ATTN_TRACE only)
+#ifdef MVLPT_ATTN_TRACE
+constexpr int ATR_MAX = 256;
+#define MVLPT_ATR(p) do { if (a.trace && blockIdx.x == 1024 && lane == 0 && atr_n < ATR_MAX) \
+    a.trace[wave * ATR_MAX + atr_n++] = ((long long)(p) << 56) | ((long long)__builtin_amdgcn_s_memtime() & 0xffffffffffffffLL); } while (0)
+#else
+#define MVLPT_ATR(p) do { } while (0)
+#endif
+
 namespace {
 constexpr int CH = 64;                 // streamed chunk / rows per workgroup
 constexpr int XIMG = CH * 128;         // one 64 x 64 16-bit image
@@ -178,6 +187,10 @@ __global__ __launch_bounds__(NW * 64) void attn32x_fwd_kernel(Attn32Args a, int 
   int nh, qcx;
   if (!map_block(a.N * a.H, nqc, nh, qcx)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+#ifdef MVLPT_ATTN_TRACE
+  int atr_n = 0;
+#endif
+  MVLPT_ATR(10);
   const int n = nh / a.H, h = nh % a.H, L = a.L, d = a.H * 64;
   const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d;
   const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
@@ -199,6 +212,7 @@ __global__ __launch_bounds__(NW * 64) void attn32x_fwd_kernel(Attn32Args a, int 
   }
   // the compiler's own wait for these loads sits here, not inside the loop (it does not see the asm-issued DMA)
   asm volatile("" ::"v"(Qh[0][0]), "v"(Qh[0][1]), "v"(Qh[1][0]), "v"(Qh[1][1]), "v"(Ql[0][0]), "v"(Ql[0][1]), "v"(Ql[1][0]), "v"(Ql[1][1]));
+  MVLPT_ATR(11);
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};      // m in raw-score units; l is this lane's share of the row sum
   f32x4 O[2][4];
 #pragma unroll
@@ -206,14 +220,22 @@ __global__ __launch_bounds__(NW * 64) void attn32x_fwd_kernel(Attn32Args a, int 
 #pragma unroll
     for (int i = 0; i < 4; ++i) O[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int c = 0; c < nch; ++c) {
+    MVLPT_ATR(1);
     if (c > 0) __builtin_amdgcn_s_barrier();                    // every wave is done with the slot chunk c+1 overwrites
-    if (c + 1 < nch) { issue(c + 1); wait_prev_chunk<NW>(); }
+    MVLPT_ATR(2);
+    if (c + 1 < nch) { issue(c + 1); MVLPT_ATR(3); wait_prev_chunk<NW>(); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MVLPT_ATR(4);
     __builtin_amdgcn_s_barrier();                               // all pieces of chunk c have landed
+    MVLPT_ATR(5);
     const char* Kh = sm + (c & 1) * 4 * XIMG;
     const int k0 = c * CH;
     f32x4 S[2][4];
     mm_rows3<T>(S, Kh, Kh + XIMG, Qh, Ql, fr, fg);
+#ifdef MVLPT_ATTN_TRACE
+    asm volatile("" ::"v"(S[0][0]), "v"(S[1][3]));
+#endif
+    MVLPT_ATR(6);
     const bool edge = CAUSAL || k0 + CH > L;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -243,8 +265,17 @@ __global__ __launch_bounds__(NW * 64) void attn32x_fwd_kernel(Attn32Args a, int 
 #pragma unroll
       for (int i = 0; i < 4; ++i) O[t][i] *= alpha;
     }
+#ifdef MVLPT_ATTN_TRACE
+    asm volatile("" ::"v"(S[0][0]), "v"(S[1][3]));
+#endif
+    MVLPT_ATR(7);
     mm_accum3<T>(O, Kh + 2 * XIMG, Kh + 3 * XIMG, S, fr, fg);
+#ifdef MVLPT_ATTN_TRACE
+    asm volatile("" ::"v"(O[0][0]), "v"(O[1][3]));
+#endif
+    MVLPT_ATR(8);
   }
+  MVLPT_ATR(12);
   const int qlim = a.q_rows > 0 ? (a.q_rows < L ? a.q_rows : L) : L;
   // rows that are not computed get lse = +huge: a backward over the full sequence then sees P = 0 there (finite), not garbage
   if (a.lse && qlim < L && qcx == 0)
@@ -260,6 +291,7 @@ __global__ __launch_bounds__(NW * 64) void attn32x_fwd_kernel(Attn32Args a, int 
       if (a.lse && fg == 0) a.lse[((size_t)n * a.H + h) * L + q[t]] = m[t] * SCALE + logf(lt);
     }
   }
+  MVLPT_ATR(13);
 }
 
 // dQ (+ delta) of the NW*32 queries starting at qcx*NW*32 of head nh.  `stat_lds` non-null: -lse*log2(e) and delta of the

@@ -1027,7 +1027,23 @@ int mvlpt_op_layernorm_bwd_split(int dtype, const void* dy, const float* x, cons
 int mvlpt_op_attention32_fwd(int dtype, const void* qkv, void* out, float* lse, int N, int L, int H, int causal, int q_rows,
                              mvlpt_stream_t stream) {
   Attn32Args a{qkv, out, lse, N, L, H, causal, q_rows};
+#ifdef MVLPT_ATTN_TRACE
+  // debug builds: timeline of one workgroup -> $MVLPT_ATTN_TRACE_FILE (8 waves x 256 int64 records)
+  const char* path = getenv("MVLPT_ATTN_TRACE_FILE");
+  long long* tr = nullptr;
+  const size_t tr_bytes = 8 * 256 * sizeof(long long);
+  if (path) { OPCHK(hipMalloc(&tr, tr_bytes)); OPCHK(hipMemsetAsync(tr, 0, tr_bytes, (hipStream_t)stream)); a.trace = tr; }
+#endif
   OPCHK(launch_attn32_fwd(dtype, a, (hipStream_t)stream));
+#ifdef MVLPT_ATTN_TRACE
+  if (path) {
+    std::vector<long long> hbuf(8 * 256);
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    OPCHK(hipMemcpy(hbuf.data(), tr, tr_bytes, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(path, "wb")) { fwrite(hbuf.data(), 1, tr_bytes, f); fclose(f); }
+    (void)hipFree(tr);
+  }
+#endif
   return 0;
 }
 int mvlpt_op_attention32_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,

@@ -113,6 +113,9 @@ struct Attn32Args {
   int N, L, H; int causal;
   int q_rows = 0;        // > 0: only queries 0..q_rows-1 of every sequence are computed
   int out_lo8 = 0;       // out_split rows are [hi(d) | lo8 (d bytes) | unused] (mixed pair: the out-projection's A operand)
+#ifdef MVLPT_ATTN_TRACE
+  long long* trace = nullptr;   // debug builds only (tools/attn_trace.py): (point id << 56 | s_memtime) records of one workgroup
+#endif
 };
 hipError_t launch_attn32_fwd(int dtype, const Attn32Args& a, hipStream_t s);
 struct Attn32BwdArgs {

@@ -1,0 +1,37 @@
+"""Timeline of ONE workgroup (block 1024: mid-launch, chip busy) of the streamed pair-attention forward (debug build with
+-DMVLPT_ATTN_TRACE, loaded through MVLPT_HIP_LIB).  Usage on the GPU box:
+    MVLPT_HIP_LIB=$PWD/mvlpt_amd/libvar_attn_trace.so python tools/attn_trace.py [N L H]
+Points: 10 kernel start, 11 own rows requested / first chunk issued, per chunk 1 loop top, 2 after the slot-free barrier, 3 after the
+DMA issue of the next chunk, 4 after the vmcnt wait, 5 after the data barrier, 6 after S = Q.K^T (3 terms), 7 after the softmax,
+8 after O += P.V (incl. the split of P), 12 epilogue start, 13 end."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MVLPT_ATTN_TRACE_FILE"] = "/tmp/attn_trace.bin"
+import numpy as np
+import torch
+from mvlpt_amd import engine as E, _lib
+N, L, H = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 205, 12)
+d = H * 64
+qkv = E.split_pair(torch.randn(N * L, 3 * d, device="cuda"), torch.float16)
+out = torch.zeros(N * L, 2 * d, device="cuda", dtype=torch.float16)
+lse = torch.zeros(N * H * L, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    _lib.lib.mvlpt_op_attention32_fwd(1, qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), N, L, H, 0, 0, st)
+torch.cuda.synchronize()
+raw = np.fromfile("/tmp/attn_trace.bin", dtype=np.int64).reshape(8, 256)
+names = {(10, 11): "prologue (Q loads, DMA chunk 0)", (11, 1): "to loop", (1, 2): "slot-free barrier", (2, 3): "DMA issue", (3, 4): "vmcnt wait",
+         (2, 4): "vmcnt wait (last)", (4, 5): "data barrier", (5, 6): "S = Q.K^T", (6, 7): "softmax", (7, 8): "P split + P.V", (8, 1): "loop",
+         (8, 12): "to epilogue", (12, 13): "epilogue"}
+for w in range(8):
+    r = raw[w][raw[w] != 0]
+    if len(r) == 0:
+        continue
+    p, t = (r >> 56) & 0xff, r & ((1 << 56) - 1)
+    seg = {}
+    for k in range(1, len(p)):
+        seg.setdefault((int(p[k - 1]), int(p[k])), []).append(int(t[k] - t[k - 1]))
+    tot = int(t[-1] - t[0])
+    print(f"wave {w}: {tot} ticks total (100 MHz ticks x ~20 = shader cycles? see below)")
+    for key, v in seg.items():
+        print(f"    {names.get(key, str(key)):34s} {np.sum(v):7d} ticks  ({100 * np.sum(v) / tot:4.1f} %)  per occurrence {np.mean(v):7.0f} x{len(v)}")
