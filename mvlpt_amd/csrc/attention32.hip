@@ -739,6 +739,228 @@ __global__ __launch_bounds__(SNT * 64, 4) void attn32t_bwd_kernel(Attn32BwdArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ resident, medium sequences
+// 80 < L <= 208, not causal (ViT-B/16 and ViT-L/14 at 224 px with their prompt tokens: 197 .. 205 and 257 is too long): the structure
+// of the short kernels above at RNT = 13 tiles — ALL of K and V (forward) or K, V and then Q, dO (backward) of one (sequence, head)
+// resident in LDS as four 208-row images (104 KiB), RNW = 7 waves that own two query (key) tiles each (tile w and tile w + 7), every
+// product straight out of LDS with no barrier inside a phase: a head costs two barriers (forward) or four (backward) instead of
+// eight / sixteen.  Measured at 256 x 12 heads, L = 205: forward 276 vs 292 us, backward 749 vs 785 us (same box, same run) — the
+// chunk barriers and DMA waits that make up 44 % of a streamed head (tools/attn_trace.py) were a symptom: what remains is staging that
+// nothing overlaps (one workgroup per CU) plus ~28 000 cycles of MFMA + VALU + LDS work per head for ~10 000 of MFMA issue.  Starting
+// the second wave of each SIMD out of phase (s_sleep 640 .. 2 560 cycles) changes nothing either.
+namespace {
+constexpr int RNT = 13, RNW = 7, RROWS = RNT * 16, RIMG = RROWS * 128;
+constexpr int RLDS = 4 * RIMG, RLDS_BWD = 4 * RIMG + 2 * RROWS * 4;
+
+template <typename T>
+__device__ __forceinline__ void stage_res(char* hi, char* lo, const T* src, size_t lo_off, size_t ld, int L, int wave, int lane) {
+  const int srow = lane >> 3, chunk = (lane & 7) ^ srow;
+  for (int sl = wave; sl < RROWS / 8; sl += RNW) {
+    int row = sl * 8 + srow;
+    row = row < L ? row : L - 1;
+    const T* g = src + (size_t)row * ld + chunk * 8;
+    dma_raw<16>(g, hi + sl * 1024);
+    dma_raw<16>(g + lo_off, lo + sl * 1024);
+  }
+}
+// p[0 .. RNT) (tiles outside [t_lo, t_hi) are zero) times the image: six full 32-row blocks and the 13th tile alone
+template <typename T>
+__device__ __forceinline__ void accum_res3(f32x4 (&out)[4], const char* hi, const char* lo, const f32x4 (&p)[RNT], int t_lo, int t_hi, int fr, int fg) {
+#pragma unroll
+  for (int kb = 0; kb < RNT / 2; ++kb)
+    if (t_lo < 2 * kb + 2 && t_hi > 2 * kb) block_accum3<T, false>(out, hi, lo, kb, p[2 * kb], p[2 * kb + 1], fr, fg);
+  if (t_hi > RNT - 1) block_accum3<T, true>(out, hi, lo, RNT / 2, p[RNT - 1], f32x4{0.f, 0.f, 0.f, 0.f}, fr, fg);
+}
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(RNW * 64) void attn32r_fwd_kernel(Attn32Args a) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char *Kh = sm, *Kl = sm + RIMG, *Vh = sm + 2 * RIMG, *Vl = sm + 3 * RIMG;
+  using v8 = typename Vec<T>::v8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+  const int n = blockIdx.y, h = blockIdx.x, L = a.L, d = a.H * 64;
+  const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d;
+  const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
+  stage_res<T>(Kh, Kl, base + d, lo, ld, L, wave, lane);
+  stage_res<T>(Vh, Vl, base + 2 * d, lo, ld, L, wave, lane);
+  const int nt = (L + 15) >> 4;
+  const int qlim = a.q_rows > 0 ? (a.q_rows < L ? a.q_rows : L) : L;
+  v8 Qh[2][2], Ql[2][2];
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const int q = (wave + o * RNW) * 16 + fr;
+    load_own_pair<T>(Qh[o], Ql[o], base + (size_t)(q < L ? q : L - 1) * ld, lo, fg);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (a.lse && qlim < L)          // rows that are not computed: lse = +huge (P = 0 in a backward over the full sequence)
+    for (int j = qlim + tid; j < L; j += RNW * 64) a.lse[((size_t)n * a.H + h) * L + j] = 3.0e38f;
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const int tile = wave + o * RNW;
+    if (tile >= nt || tile * 16 >= qlim) continue;
+    const int q = tile * 16 + fr;
+    f32x4 S[RNT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < RNT; ++kt) {
+      S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < nt) {
+        S[kt] = tile_rows3<T>(Kh, Kl, kt, Qh[o], Ql[o], fr, fg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = 16 * kt + 4 * fg + r;
+          S[kt][r] = kk < L ? S[kt][r] : -INFINITY;
+          mx = fmaxf(mx, S[kt][r]);
+        }
+      }
+    }
+    mx = quad_max(mx);
+    const float msc = mx * SC2;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < RNT; ++kt)
+      if (kt < nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { S[kt][r] = __builtin_amdgcn_exp2f(fmaf(S[kt][r], SC2, -msc)); sum += S[kt][r]; }
+      }
+    sum = quad_sum(sum);
+    f32x4 O[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accum_res3<T>(O, Vh, Vl, S, 0, nt, fr, fg);
+    if (q < qlim) {
+      const float inv = 1.f / sum;
+      T* orow = (T*)a.out_split + ((size_t)n * L + q) * (2 * (size_t)d) + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store_pair4_m<T>(orow + 16 * dt + 4 * fg, d, h * 64 + 16 * dt + 4 * fg, O[dt] * inv, a.out_lo8);
+      if (a.lse && fg == 0) a.lse[((size_t)n * a.H + h) * L + q] = mx * SCALE + logf(sum);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(RNW * 64) void attn32r_bwd_kernel(Attn32BwdArgs a) {
+  // phase A: K, V resident, the waves own query tiles -> dQ; phase B: Q, dO resident, the waves own key tiles -> dK, dV
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  char *I0h = sm, *I0l = sm + RIMG, *I1h = sm + 2 * RIMG, *I1l = sm + 3 * RIMG;
+  float* nlse_s = (float*)(sm + 4 * RIMG);
+  float* del_s = nlse_s + RROWS;
+  using v8 = typename Vec<T>::v8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+  const int n = blockIdx.y, h = blockIdx.x, L = a.L, d = a.H * 64;
+  const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d, gld = 2 * (size_t)d;
+  const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
+  const T* gbase = (const T*)a.dout_split + (size_t)n * L * gld + h * 64;
+  stage_res<T>(I0h, I0l, base + d, lo, ld, L, wave, lane);          // K
+  stage_res<T>(I1h, I1l, base + 2 * d, lo, ld, L, wave, lane);      // V
+  const size_t stat0 = ((size_t)n * a.H + h) * L;
+  const int nt = (L + 15) >> 4;
+  float nlse[2], dl[2];       // of the own query rows: -lse * log2(e), delta = rowsum(dO * O)
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const int row = (wave + o * RNW) * 16 + fr, rc = row < L ? row : L - 1;
+    const T* orow = (const T*)a.out_split + ((size_t)n * L + rc) * gld + h * 64;
+    const T* grow = gbase + (size_t)rc * gld;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 ov = load_pair4_m<T>(orow + 16 * t + 4 * fg, d, h * 64 + 16 * t + 4 * fg, a.lo8), g = load_pair4<T>(grow + 16 * t + 4 * fg, d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc += ov[e] * g[e];
+    }
+    dl[o] = quad_sum(acc);
+    nlse[o] = -a.lse[stat0 + rc] * LOG2E;
+    if (fg == 0 && row < RROWS) { nlse_s[row] = nlse[o]; del_s[row] = dl[o]; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- phase A: own query tiles -> dQ
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const int tile = wave + o * RNW;
+    if (tile >= nt) continue;
+    const int row = tile * 16 + fr, rc = row < L ? row : L - 1;
+    v8 Qh[2], Ql[2], Gh[2], Gl[2];
+    load_own_pair<T>(Qh, Ql, base + (size_t)rc * ld, lo, fg);
+    load_own_pair<T>(Gh, Gl, gbase + (size_t)rc * gld, d, fg);
+    f32x4 dS[RNT];
+#pragma unroll
+    for (int kt = 0; kt < RNT; ++kt) {
+      dS[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < nt) {
+        const f32x4 S = tile_rows3<T>(I0h, I0l, kt, Qh, Ql, fr, fg);
+        const f32x4 dP = tile_rows3<T>(I1h, I1l, kt, Gh, Gl, fr, fg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = 16 * kt + 4 * fg + r;
+          const float p = kk < L ? __builtin_amdgcn_exp2f(fmaf(S[r], SC2, nlse[o])) : 0.f;
+          dS[kt][r] = p * (dP[r] - dl[o]);
+        }
+      }
+    }
+    f32x4 dQ[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dQ[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accum_res3<T>(dQ, I0h, I0l, dS, 0, nt, fr, fg);
+    if (row < L) {
+      T* orow = (T*)a.dqkv_split + ((size_t)n * L + row) * ld + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store_pair4_m<T>(orow + 16 * dt + 4 * fg, lo, h * 64 + 16 * dt + 4 * fg, dQ[dt] * SCALE, a.lo8);
+    }
+  }
+  __syncthreads();
+  stage_res<T>(I0h, I0l, base, lo, ld, L, wave, lane);              // Q
+  stage_res<T>(I1h, I1l, gbase, d, gld, L, wave, lane);             // dO
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- phase B: own key tiles -> dK, dV
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const int tile = wave + o * RNW;
+    if (tile >= nt) continue;
+    const int row = tile * 16 + fr, rc = row < L ? row : L - 1;
+    v8 Kh[2], Kl[2], Vh[2], Vl[2];
+    load_own_pair<T>(Kh, Kl, base + d + (size_t)rc * ld, lo, fg);
+    load_own_pair<T>(Vh, Vl, base + 2 * d + (size_t)rc * ld, lo, fg);
+    f32x4 P[RNT], dS[RNT];
+#pragma unroll
+    for (int qt = 0; qt < RNT; ++qt) {
+      P[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dS[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (qt < nt) {
+        const f32x4 S = tile_rows3<T>(I0h, I0l, qt, Kh, Kl, fr, fg);      // lane: [key = fr][query = 16qt + 4fg + r]
+        const f32x4 dP = tile_rows3<T>(I1h, I1l, qt, Vh, Vl, fr, fg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq = 16 * qt + 4 * fg + r;
+          const float p = qq < L ? __builtin_amdgcn_exp2f(fmaf(S[r], SC2, nlse_s[qq])) : 0.f;
+          P[qt][r] = p;
+          dS[qt][r] = p * (dP[r] - del_s[qq]);
+        }
+      }
+    }
+    f32x4 dK[4], dV[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dK[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    accum_res3<T>(dV, I1h, I1l, P, 0, nt, fr, fg);
+    accum_res3<T>(dK, I0h, I0l, dS, 0, nt, fr, fg);
+    if (row < L) {
+      T* orow = (T*)a.dqkv_split + ((size_t)n * L + row) * ld + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        store_pair4_m<T>(orow + d + 16 * dt + 4 * fg, lo, d + h * 64 + 16 * dt + 4 * fg, dK[dt] * SCALE, a.lo8);
+        store_pair4_m<T>(orow + 2 * d + 16 * dt + 4 * fg, lo, 2 * d + h * 64 + 16 * dt + 4 * fg, dV[dt], a.lo8);
+      }
+    }
+  }
+}
+static bool attn32_resident(int L, int causal) {
+  static const bool on = !(getenv("MVLPT_ATTN32_RESIDENT") && atoi(getenv("MVLPT_ATTN32_RESIDENT")) == 0);
+  return on && !causal && L <= RROWS;
+}
+
 // workgroup height: 8 waves (256 own rows) stream the other side fewer times; 4 waves (128 rows) pad less.
 // MVLPT_ATTN32_NW = 4 / 8 forces one (experiments)
 static int attn32_nw(int rows) {
@@ -789,6 +1011,12 @@ static hipError_t fwd_t(const Attn32Args& a, hipStream_t s) {
     else hipLaunchKernelGGL((attn32t_fwd_kernel<T, false>), grid, block, 0, s, a);
     return hipGetLastError();
   }
+  if (attn32_resident(a.L, a.causal)) {
+    static bool set = false;
+    if (!set) { set_lds(attn32r_fwd_kernel<T>, RLDS); set = true; }
+    hipLaunchKernelGGL((attn32r_fwd_kernel<T>), dim3(a.H, a.N), dim3(RNW * 64), RLDS, s, a);
+    return hipGetLastError();
+  }
   const int lq = a.q_rows > 0 ? (a.q_rows < a.L ? a.q_rows : a.L) : a.L;
   if (attn32_nw(lq) == 8) return a.causal ? fwd_x<T, true, 8>(a, s) : fwd_x<T, false, 8>(a, s);
   return a.causal ? fwd_x<T, true, 4>(a, s) : fwd_x<T, false, 4>(a, s);
@@ -799,6 +1027,12 @@ static hipError_t bwd_t(const Attn32BwdArgs& a, hipStream_t s) {
     dim3 grid(a.H, a.N), block(SNT * 64);
     if (a.causal) hipLaunchKernelGGL((attn32t_bwd_kernel<T, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((attn32t_bwd_kernel<T, false>), grid, block, 0, s, a);
+    return hipGetLastError();
+  }
+  if (attn32_resident(a.L, a.causal)) {
+    static bool set = false;
+    if (!set) { set_lds(attn32r_bwd_kernel<T>, RLDS_BWD); set = true; }
+    hipLaunchKernelGGL((attn32r_bwd_kernel<T>), dim3(a.H, a.N), dim3(RNW * 64), RLDS_BWD, s, a);
     return hipGetLastError();
   }
   if (a.L > 8192) return hipErrorInvalidValue;       // the dK/dV kernel keeps lse and delta of a whole sequence in LDS
