@@ -782,8 +782,10 @@ __global__ __launch_bounds__(RNW * 64) void attn32r_fwd_kernel(Attn32Args a) {
   const int n = blockIdx.y, h = blockIdx.x, L = a.L, d = a.H * 64;
   const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d;
   const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
+#if !defined(MVLPT_ABL) || MVLPT_ABL != 2      // ablation 2: no staging (compute on whatever LDS holds)
   stage_res<T>(Kh, Kl, base + d, lo, ld, L, wave, lane);
   stage_res<T>(Vh, Vl, base + 2 * d, lo, ld, L, wave, lane);
+#endif
   const int nt = (L + 15) >> 4;
   const int qlim = a.q_rows > 0 ? (a.q_rows < L ? a.q_rows : L) : L;
   v8 Qh[2][2], Ql[2][2];
@@ -806,7 +808,11 @@ __global__ __launch_bounds__(RNW * 64) void attn32r_fwd_kernel(Attn32Args a) {
 #pragma unroll
     for (int kt = 0; kt < RNT; ++kt) {
       S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if defined(MVLPT_ABL) && MVLPT_ABL == 1       // ablation 1: no arithmetic (staging, own rows, stores only)
+      if (false) {
+#else
       if (kt < nt) {
+#endif
         S[kt] = tile_rows3<T>(Kh, Kl, kt, Qh[o], Ql[o], fr, fg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -829,7 +835,9 @@ __global__ __launch_bounds__(RNW * 64) void attn32r_fwd_kernel(Attn32Args a) {
     f32x4 O[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if !defined(MVLPT_ABL) || MVLPT_ABL != 1
     accum_res3<T>(O, Vh, Vl, S, 0, nt, fr, fg);
+#endif
     if (q < qlim) {
       const float inv = 1.f / sum;
       T* orow = (T*)a.out_split + ((size_t)n * L + q) * (2 * (size_t)d) + h * 64;
