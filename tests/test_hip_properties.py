@@ -251,9 +251,7 @@ def test_cfg3_vpt_deep_1000_classes_batch_256():
         full = model(x)
         halves = torch.cat([model(x[:128].contiguous()), model(x[128:].contiguous())])
     assert torch.equal(halves, full)
-    # (the inference forward keeps single 16-bit operands through 24 layers of 581 tokens: measured 1.1e-3 of max|logit| against the
-    # split-operand training forward, which itself sits 3e-5 from the reference (full_vitl14_336 fixture); PREC = "fp32" removes it)
-    assert float((full - l0).abs().max()) <= 2e-3 * float(l0.abs().max()), "training and inference forwards agree to 2e-3"
+    assert float((full - l0).abs().max()) <= 1e-3 * float(l0.abs().max()), "training and inference forwards agree to 1e-3"
     # cross-entropy at C = 1000 against torch on the same logits
     ref = torch.nn.functional.cross_entropy(l0, y)
     assert abs(float(ref) - s0) < 1e-5 * max(1.0, s0)
@@ -347,4 +345,6 @@ def test_cfg5_vitl14_336_upt_1151_classes_batch_128():
         full = model(x)
         halves = torch.cat([model(x[:64].contiguous()), model(x[64:].contiguous())])
     assert torch.equal(halves, full)
-    assert float((full - l0).abs().max()) <= 1e-3 * float(l0.abs().max()), "training and inference forwards agree to 1e-3"
+    # (the inference forward keeps single 16-bit operands through 24 layers of 581 tokens: measured 1.1e-3 of max|logit| against the
+    # split-operand training forward, which itself sits 3e-5 from the reference (full_vitl14_336 fixture); PREC = "fp32" removes it)
+    assert float((full - l0).abs().max()) <= 2e-3 * float(l0.abs().max()), "training and inference forwards agree to 2e-3"
