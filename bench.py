@@ -216,6 +216,9 @@ def main():
     ap.add_argument("--grad-precision", default="split_grad", choices=["split_grad", "fast"],
                     help="split_grad (default): hi+lo operand pairs (GEMMs and attention) in towers that carry a gradient (prompt "
                          "gradients within 1e-3 of the fp32 CPU path); fast: single 16-bit operands everywhere (~4e-3)")
+    ap.add_argument("--text-cus", type=int, default=None,
+                    help="compute units of the text tower's partition when the two towers run side by side (CustomCLIP.set_cu_partition; "
+                         "0 = shared streams); default: the library's (MVLPT_TEXT_CUS / model.DEFAULT_TEXT_CUS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--all-kernel-timing", action="store_true", help="bracket every kernel class with marker events (slower)")
@@ -279,12 +282,16 @@ def main():
     dm.train_loader_x = _CyclingLoader(dm.train_loader_x, W + K + 1)
     trainer = MVLPT(cfg, dm=dm, clip_state_dict=sd)
     trainer.model.trim_text_to_eot = args.trim_eot
+    if args.text_cus is not None:
+        trainer.model.set_cu_partition(args.text_cus)
     if args.shard_text is None:
         args.shard_text = world > 1 and args.classes >= 1000 and n_ctx > 0
     if args.shard_text and world > 1:
         trainer.model.enable_class_sharding(rank, world)
     L_text = trainer.model.prompt_learner.tokenized_prompts.shape[1]
     eng = trainer.model.engine
+    from mvlpt_amd.engine import device_cus
+    eng_cus = device_cus(dev)
     pipeline = cfg.TRAINER.MVLPT.STEP_PIPELINING and n_vpt == 0
 
     # The timed region is K steps of the trainer's OWN loop (TrainerX.run_epoch, which reads the loader one batch ahead):
@@ -394,6 +401,8 @@ def main():
                        "text_positions_evaluated": (trainer.model.prompt_learner.max_eot + 1) if args.trim_eot else L_text,
                        "loop": "TrainerX.run_epoch = the plain Dassl loop `for batch in train_loader_x: forward_backward(batch)`; the one-batch look-ahead comes from the loader (LookAheadLoader, installed by MVLPT.build_data_loader)", "step_pipelining": bool(pipeline),
                        "grad_precision": args.grad_precision,
+                       "cu_partition": ({"text_tower_cus": trainer.model.text_cus, "image_tower_cus": eng_cus - trainer.model.text_cus}
+                                        if trainer.model.text_cus else "none (towers share every compute unit)"),
                        "per_gpu_batch": args.batch, "global_batch": B_global, "parallelism": f"dp{world}",
                        "text_tower": "class-sharded over ranks" if (args.shard_text and world > 1) else "replicated per GPU", "loss": round(loss, 5)},
             "step_mfma_fraction": round(ips / world * gf_img / (MFMA_PEAK_TFLOPS * 1e3), 4),

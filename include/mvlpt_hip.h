@@ -61,6 +61,18 @@ int mvlpt_destroy(void* handle);
 const char* mvlpt_last_error(void* handle); /* handle may be NULL for create() failures */
 const char* mvlpt_version(void);
 
+/* Streams confined to a partition of the compute units.  The reference runs the two towers one after the other on one
+ * stream (`image_features = self.image_encoder(...)`, `text_features = self.text_encoder(...)`, trainers/mvlpt.py:543-548);
+ * here they are independent until the logits and run side by side.  The image tower's persistent GEMM workgroups hold
+ * every CU they are given for the whole launch, so the text tower's short, wide kernels would only ever run in their
+ * tails: a stream from mvlpt_stream_create_cus owns logical compute units [cu_first, cu_first + cu_count)
+ * (hipExtStreamCreateWithCUMask; logical CU i sits on XCD i % 8, so a multiple of 8 is the same share of every XCD), and
+ * every launcher of this library sizes persistent / grid-stride grids by the stream's partition (mvlpt_stream_cus: the
+ * partition size, or the device's CU count for any other stream).  Any hipStream_t still works everywhere. */
+int mvlpt_stream_create_cus(int cu_first, int cu_count, mvlpt_stream_t* stream);
+int mvlpt_stream_destroy(mvlpt_stream_t stream);
+int mvlpt_stream_cus(mvlpt_stream_t stream);
+
 /* Frozen weights (replaces `self.model.to(self.device)` for the CLIP towers, trainers/mvlpt.py:867, with a
  * one-time pack: 16-bit copy for the forward GEMM and a pre-transposed copy for the dX GEMM — legal because
  * every non-prompt parameter is frozen, trainers/mvlpt.py:855-858).  `name` is the key of

@@ -49,6 +49,9 @@ SIGNATURES = {
     "mvlpt_trim": (_i, [_vp]),
     "mvlpt_last_error": (C.c_char_p, [_vp]),
     "mvlpt_version": (C.c_char_p, []),
+    "mvlpt_stream_create_cus": (_i, [_i, _i, C.POINTER(_vp)]),
+    "mvlpt_stream_destroy": (_i, [_vp]),
+    "mvlpt_stream_cus": (_i, [_vp]),
     "mvlpt_load_frozen": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i, _vp]),
     "mvlpt_frozen_ready": (_i, [_vp]),
     "mvlpt_image_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),

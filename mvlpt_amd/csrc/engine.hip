@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,35 @@
 #include "kernels.h"
 
 using namespace mvlpt;
+
+// ------------------------------------------------------------------------------------------------ CU-partitioned streams
+// A stream made by mvlpt_stream_create_cus only ever gets the compute units of its mask; everything that sizes a grid by
+// "resident workgroups" (persistent GEMM, grid-stride LayerNorm) asks stream_cus() instead of the device.  A handful of
+// streams per process: a linear scan under a mutex costs nothing next to a launch.
+
+namespace {
+struct StreamPart { hipStream_t s; int cus; };
+std::mutex g_part_mu;
+std::vector<StreamPart> g_parts;
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  return cus;
+}
+}  // namespace
+namespace mvlpt {
+int stream_cus(hipStream_t s) {
+  if (s) {
+    std::lock_guard<std::mutex> lk(g_part_mu);
+    for (const StreamPart& p : g_parts) if (p.s == s) return p.cus;
+  }
+  return device_cus();
+}
+}  // namespace mvlpt
 
 namespace {
 
@@ -470,6 +500,37 @@ int mvlpt_set_precision(void* h, int mode) {
   E->prec_mode = mode;
   return 0;
 }
+
+int mvlpt_stream_create_cus(int cu_first, int cu_count, mvlpt_stream_t* stream) {
+  if (!stream) return fail(nullptr, MVLPT_ERR_ARG, "stream_create_cus: null argument");
+  const int total = device_cus();
+  if (cu_first < 0 || cu_count <= 0 || cu_first + cu_count > total)
+    return fail(nullptr, MVLPT_ERR_ARG, "stream_create_cus: CU range outside the device (" + std::to_string(total) + " compute units)");
+  // bit i of the mask = logical compute unit i; the driver deals logical CUs round-robin over the XCDs (bit i -> XCD i % 8),
+  // so a contiguous range of 8k bits is k compute units on EVERY XCD: each partition keeps all eight L2s
+  std::vector<uint32_t> mask((total + 31) / 32, 0u);
+  for (int i = cu_first; i < cu_first + cu_count; ++i) mask[i >> 5] |= 1u << (i & 31);
+  hipStream_t s = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
+  if (e != hipSuccess) return hipfail(nullptr, e, "hipExtStreamCreateWithCUMask");
+  { std::lock_guard<std::mutex> lk(g_part_mu); g_parts.push_back(StreamPart{s, cu_count}); }
+  *stream = (mvlpt_stream_t)s;
+  return 0;
+}
+
+int mvlpt_stream_destroy(mvlpt_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!s) return 0;
+  {
+    std::lock_guard<std::mutex> lk(g_part_mu);
+    for (size_t i = 0; i < g_parts.size(); ++i) if (g_parts[i].s == s) { g_parts.erase(g_parts.begin() + i); break; }
+  }
+  hipError_t e = hipStreamDestroy(s);
+  if (e != hipSuccess) return hipfail(nullptr, e, "hipStreamDestroy");
+  return 0;
+}
+
+int mvlpt_stream_cus(mvlpt_stream_t stream) { return stream_cus((hipStream_t)stream); }
 
 int mvlpt_trim(void* h) {
   Engine* E = (Engine*)h;

@@ -609,12 +609,7 @@ static hipError_t launch_phased(const GemmArgs& g, hipStream_t s, hipEvent_t ea,
     (void)hipFuncSetAttribute((const void*)gemm_bt_phased_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  }
+  const int cus = stream_cus(s);
   const int tiles = ((g.M + 255) / 256) * (g.N / 128);
   hipExtLaunchKernelGGL((gemm_bt_phased_kernel<T, EPI>), dim3(tiles < cus ? tiles : cus), dim3(512), LDS, s, ea, eb, 0, g);
   return hipGetLastError();
@@ -628,15 +623,10 @@ static hipError_t launch_geo_m(const GemmArgs& g, int wg_per_cu, hipStream_t s, 
     (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  int cus = stream_cus(s);
 #ifdef MVLPT_DEBUG_CUS
-    if (getenv("MVLPT_DBG_CUS")) cus = atoi(getenv("MVLPT_DBG_CUS"));      // CU-scaling measurement, debug builds only
+  if (getenv("MVLPT_DBG_CUS")) cus = atoi(getenv("MVLPT_DBG_CUS"));      // CU-scaling measurement, debug builds only
 #endif
-  }
   const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
   const int resident = cus * wg_per_cu;
   hipExtLaunchKernelGGL((gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), LDS, s,
@@ -650,16 +640,6 @@ static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hi
     if (g.a_split == 2) return launch_geo_m<T, EPI, BM_, BN_, NW, NS, true>(g, wg_per_cu, s, ea, eb);
   } else if (g.a_split == 2) return hipErrorInvalidValue;
   return launch_geo_m<T, EPI, BM_, BN_, NW, NS, false>(g, wg_per_cu, s, ea, eb);
-}
-
-static int num_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  }
-  return cus;
 }
 
 // rows [m_lo, m_lo + rows) of the problem as a GEMM of its own (all operands are row-major with leading dimension
@@ -692,9 +672,12 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   // 256x256 needs >= 4 rounds of tiles, or >= 2 rounds when K is long (a ragged last round then costs less than the
   // smaller geometry's extra LDS traffic: N = 768, K = 3072: 315 -> 297 us with 2.3 rounds)
   const int Keff = g.a_split == 2 ? g.K + g.K / 2 : (g.a_split ? 2 * g.K : g.K);
-  const bool big = g.N % 256 == 0 && (t256 >= 1024 || (t256 >= 512 && Keff >= 2048));
+  // the round counts below are per compute unit the stream can use (a CU-partitioned stream: mvlpt_stream_create_cus)
+  const long cus = stream_cus(s);
+  const bool big = g.N % 256 == 0 && (t256 >= 4 * cus || (t256 >= 2 * cus && Keff >= 2048));
+  const bool r15 = 2 * t128 >= 3 * cus;      // >= 1.5 rounds of 256x128 tiles
   // (the phased kernel has no fp8 stages: mixed pairs take the plain 256x128 geometry)
-  if (g.a_split != 2 && t128 >= 384 && (phased == 1 || (phased == 2 && Keff >= 2048 && !big))) {
+  if (g.a_split != 2 && r15 && (phased == 1 || (phased == 2 && Keff >= 2048 && !big))) {
     *tile_m = 256; *tile_n = 128;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_phased<T, EPI>(g, s, ea, eb);
   }
@@ -702,7 +685,7 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
     *tile_m = 256; *tile_n = 256;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
   }
-  if (geo >= 1 && t128 >= 384) {
+  if (geo >= 1 && r15) {
     *tile_m = 256; *tile_n = 128;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 128, 8, 3>(g, 1, s, ea, eb);
   }
@@ -712,7 +695,7 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   // (its 128 KiB workgroups cannot share a CU with the image-tower kernels they overlap with) -> off.  Round 2 (split operands
   // double every K of the text tower): tower alone 5.57 -> 5.10 ms, overlapped step 15.22 -> 15.00 ms -> on.
   const long t_small = (long)((g.M + 127) / 128) * (g.N / 128);
-  if (deep && g.a_split && t_small <= num_cus()) {
+  if (deep && g.a_split && t_small <= cus) {
     *tile_m = 128; *tile_n = 128;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 128, 128, 4, 4>(g, 1, s, ea, eb);
   }
@@ -730,7 +713,7 @@ static hipError_t launch_t(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipE
   (void)launch_one<T, EPI>(g, s, (hipEvent_t)-1, nullptr, &bm, &bn);      // query the geometry only
   static const int split = getenv("MVLPT_GEMM_TAILSPLIT") ? atoi(getenv("MVLPT_GEMM_TAILSPLIT")) : 0;   // measured: +2 % / -8 % by shape -> off
   if (split && bm == 256) {
-    const int cus = num_cus();
+    const int cus = stream_cus(s);
     const long tn = g.N / bn, tm = (g.M + bm - 1) / bm, tiles = tm * tn;
     const long full = tiles / cus;
     const double frac = (double)(tiles - full * cus) / cus;

@@ -5,6 +5,11 @@
 
 namespace mvlpt {
 
+// ---------------------------------------------------------------- streams with a compute-unit partition (engine.hip)
+// Compute units the kernels of `s` can run on: the partition size for a stream made by mvlpt_stream_create_cus, the whole
+// device otherwise.  Persistent / grid-stride launchers size their grids from it.
+int stream_cus(hipStream_t s);
+
 // ---------------------------------------------------------------- GEMM  C = A * Bt^T (+ epilogue)
 enum GemmEpi {
   EPI_STORE16 = 0,  // out16 = acc (+bias)

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void ln_fwd_stream_kernel(LnFwdArgs a) {
 
 template <typename TO>
 static void launch_ln_fwd_stream(const LnFwdArgs& a, hipStream_t s) {
-  static const int cus = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int cus = stream_cus(s);
   static const int per_cu = [] { const char* e = getenv("MVLPT_LN_BLOCKS_PER_CU"); return e ? atoi(e) : 8; }();
   const int want = (a.rows + 3) / 4;
   dim3 grid(want < cus * per_cu ? want : cus * per_cu), block(256);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void ln_bwd_stream_kernel(LnBwdArgs a) {
 
 template <typename TDY, typename T>
 static void launch_ln_bwd_stream(const LnBwdArgs& a, hipStream_t s) {
-  static const int cus = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  const int cus = stream_cus(s);
   static const int per_cu = [] { const char* e = getenv("MVLPT_LNB_BLOCKS_PER_CU"); return e ? atoi(e) : 8; }();
   const int want = (a.rows + 3) / 4;
   dim3 grid(want < cus * per_cu ? want : cus * per_cu), block(256);

@@ -39,6 +39,27 @@ def _on_device(fn):
     return wrapped
 
 
+_PARTITION_STREAMS: Dict[Tuple[int, int, int], "torch.cuda.ExternalStream"] = {}
+
+
+def partition_stream(device: torch.device, cu_first: int, cu_count: int) -> "torch.cuda.Stream":
+    """A torch view of a stream that owns logical compute units [cu_first, cu_first + cu_count) of `device`
+    (mvlpt_stream_create_cus, include/mvlpt_hip.h).  One stream per (device, range), kept for the life of the process."""
+    key = (device.index, cu_first, cu_count)
+    st = _PARTITION_STREAMS.get(key)
+    if st is None:
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.mvlpt_stream_create_cus(cu_first, cu_count, C.byref(h)), None, "stream_create_cus")
+        st = _PARTITION_STREAMS[key] = torch.cuda.ExternalStream(h.value, device=device)
+    return st
+
+
+def device_cus(device: torch.device) -> int:
+    with torch.cuda.device(device):
+        return int(lib.mvlpt_stream_cus(None))
+
+
 def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a CUDA/HIP tensor: mvlpt_amd has no CPU path")

@@ -14,6 +14,7 @@ copies; the reference keeps fp16 parameters and has no loss scaling); CoCoOp (CO
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from functools import reduce
 from operator import mul
@@ -24,6 +25,10 @@ import torch.nn as nn
 
 from .engine import Engine
 from .weights import ClipArch, _randn, arch_from_state_dict
+
+# compute units of the text tower's partition in the two-tower pipeline (CustomCLIP.set_cu_partition); 0 = no partition.
+# Overridden by the environment variable MVLPT_TEXT_CUS.
+DEFAULT_TEXT_CUS = 0
 
 SOT_TOKEN, EOT_TOKEN = 49406, 49407     # clip/simple_tokenizer.py: <|startoftext|>, <|endoftext|>
 X_TOKEN = 343                            # "X" placeholder word (trainers/mvlpt.py:227), from tests/golden/tokens.npz
@@ -501,7 +506,19 @@ class _PromptedClipFn(torch.autograd.Function):
             else:
                 dctx = dloc
         elif fctx.need_txt:
-            dctx = eng.text_bwd(dtxt)
+            part = fctx.model._text_partition
+            if part is not None and not fctx.need_img:
+                # CU partition (set_cu_partition): the backward of the text tower stays on the text stream's compute units,
+                # next to the image tower of the following batch on the prefetch stream's
+                main = torch.cuda.current_stream()
+                part.wait_stream(main)
+                with torch.cuda.stream(part):
+                    dctx = eng.text_bwd(dtxt)
+                dtxt.record_stream(part)
+                main.wait_stream(part)
+                dctx.record_stream(main)
+            else:
+                dctx = eng.text_bwd(dtxt)
         if fctx.need_img:
             dvpt, ddeep = eng.image_bwd(dimg)
             dvpt = dvpt.view(fctx.vpt_shape)
@@ -547,6 +564,10 @@ class CustomCLIP(nn.Module):
         self._prefetched = None
         self._fwd_generation = 0
         self._side_stream = torch.cuda.Stream(device=clip_model.device) if torch.cuda.is_available() else None
+        self._text_partition = None
+        self.text_cus = 0
+        if self._side_stream is not None:
+            self.set_cu_partition(int(os.environ.get("MVLPT_TEXT_CUS", DEFAULT_TEXT_CUS)))
         self.multi_task_label_pertask = cfg.DATASET.MULTITASK_LABEL_PERTASK
         if self.multi_task_label_pertask:
             # indexed by task id; sized num_classes as in the reference (:529-537)
@@ -569,6 +590,28 @@ class CustomCLIP(nn.Module):
         if world > C:
             raise ValueError(f"class sharding needs at least one class per rank ({C} classes, {world} ranks)")
         self._class_shard = ClassShard(rank, class_shard_bounds(C, world), self.clip_model.device)
+
+    def set_cu_partition(self, text_cus: int) -> None:
+        """Run the two towers on disjoint compute units (methods without visual prompts, i.e. the cross-step pipeline of
+        prefetch_image_features): the text tower forward AND backward on a stream that owns logical CUs [0, text_cus), the
+        image tower of the following batch on a stream that owns the rest (include/mvlpt_hip.h: mvlpt_stream_create_cus).
+        Without it the image tower's persistent GEMM workgroups hold every CU for a whole launch and the text tower's short
+        kernels only run in their tails (measured: each stretches ~3x, only 1.7 of 4.4 ms hide).  0 switches it off."""
+        from .engine import device_cus, partition_stream
+        dev = self.clip_model.device
+        pl = self.prompt_learner
+        if text_cus <= 0 or pl.vpt_embeddings is not None or pl.coop_n_ctx == 0:
+            if self._text_partition is not None:
+                self._side_stream = torch.cuda.Stream(device=dev)
+                self._prefetch_stream = None
+            self._text_partition, self.text_cus = None, 0
+            return
+        total = device_cus(dev)
+        text_cus = min(max(8, text_cus // 8 * 8), total - 8)       # whole CUs of every XCD on both sides
+        torch.cuda.synchronize(dev)
+        self._side_stream = self._text_partition = partition_stream(dev, 0, text_cus)
+        self._prefetch_stream = partition_stream(dev, text_cus, total - text_cus)
+        self.text_cus = text_cus
 
     def prefetch_image_features(self, image) -> bool:
         """Software pipelining across steps: with no visual prompts the image tower is a pure function of the image

@@ -16,6 +16,7 @@ Fixture kinds:
   tiny_<case>.npz          inputs, prompt-learner state, token ids, layout -> logits/loss/grads
   full_<case>.npz          ViT-B/32 / ViT-B/16 output-only (weights regenerated from the seed)
   tokens.npz               clip.tokenize ids / name_lens / EOT positions (bit-exact integers)
+  full_vitb32_coop_trainer.npz   (`coop`) the same ViT-B/32 CoOp case through trainers/coop.py's own classes
 """
 from __future__ import annotations
 
@@ -242,6 +243,44 @@ def make_full(mv, cm):
                      vpt_deep=True, cut_contextlen=True, **common)
 
 
+def run_coop_trainer_case(cm, golden_name="full_vitb32_coop_end", arch_name="ViT-B/32"):
+    """BASELINE configs[0] is `--trainer CoOp`, i.e. trainers/coop.py — its OWN PromptLearner / TextEncoder / CustomCLIP
+    (trainers/coop.py:45-80, 83-212, 215-260), not the MVLPT trainer with VPT.N_CTX = 0 that `full_vitb32_coop_end.npz` was
+    generated through.  Instantiate that class on the same frozen weights, give it the fixture's context vectors (the two
+    constructors draw their random initialisations in a different order), run forward + F.cross_entropy + backward on the
+    fixture's inputs and return what it computes."""
+    import importlib
+    ref_shim.install()
+    coop = importlib.import_module("trainers.coop")
+    arch = ARCHS[arch_name]
+    clip_model, _ = build_ref_clip(cm, arch, FULL_SEED)
+    z = np.load(os.path.join(OUT, golden_name + ".npz"))
+    cfg = ref_shim.make_cfg(input_size=arch.image_resolution, coop_n_ctx=int(z["meta_coop_n_ctx"]),
+                            class_token_position=str(z["meta_position"]))
+    cfg.TRAINER.COOP = cfg.TRAINER.MVLPT.COOP           # trainers/coop.py reads TRAINER.COOP.* (train.py:105-112)
+    cc = coop.CustomCLIP(cfg, CLASSNAMES, clip_model)
+    for n_, p in cc.named_parameters():
+        p.requires_grad_("prompt_learner" in n_)           # trainers/coop.py:300-302
+    pl = cc.prompt_learner
+    with torch.no_grad():
+        pl.ctx.copy_(torch.from_numpy(z["param_ctx"]))
+    assert np.array_equal(pl.tokenized_prompts.numpy(), z["tokenized_prompts"])
+    g = torch.Generator().manual_seed(int(z["image_seed"]))        # run_case's input stream
+    image = torch.randn(len(z["label"]), 3, arch.image_resolution, arch.image_resolution, generator=g)
+    label = torch.from_numpy(z["label"])
+    logits = cc(image)
+    loss = F.cross_entropy(logits, label)
+    loss.backward()
+    return {"out_logits": logits.detach().numpy(), "out_loss": loss.detach().numpy(), "grad_ctx": pl.ctx.grad.numpy(),
+            "param_ctx": z["param_ctx"], "label": z["label"], "image_seed": z["image_seed"]}
+
+
+def make_coop_trainer(cm):
+    d = run_coop_trainer_case(cm)
+    np.savez_compressed(os.path.join(OUT, "full_vitb32_coop_trainer.npz"), **d)
+    print(f"[golden] full_vitb32_coop_trainer (trainers/coop.py): loss {float(d['out_loss']):.6f}")
+
+
 def make_large(mv, cm):
     """BASELINE cfg5 family: ViT-L/14@336px (581 vision tokens with 4 prompts, 24 layers, width 1024; text width 768)."""
     arch = ARCHS["ViT-L/14@336px"]
@@ -375,6 +414,8 @@ def main():
         make_full(mv, cm)
     if "large" in which:
         make_large(mv, cm)
+    if "coop" in which:
+        make_coop_trainer(cm)
 
 
 if __name__ == "__main__":
