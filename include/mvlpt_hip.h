@@ -43,7 +43,10 @@ typedef struct MvlptArch {
  *   MVLPT_PREC_FAST       single 16-bit operands everywhere (prompt gradients within ~4e-3 of the fp32 CPU path)
  *   MVLPT_PREC_SPLIT_GRAD default: a tower whose forward is saved for a backward runs with SPLIT operands — every GEMM A
  *                         operand is hi = round16(x) plus its rounding residual as one e5m2 byte (the "mixed pair" below: the
- *                         residual term runs on the fp8 MFMA against an e4m3 copy of the frozen weight, ~2^-16 of the value),
+ *                         residual term runs on the fp8 MFMA against an e4m3 copy of the frozen weight: e5m2 keeps 2 mantissa bits
+ *                         of a residual that is <= 2^-11 |x| (fp16) / 2^-8 |x| (bf16), e4m3 3 bits of the weight, so an operand is
+ *                         carried to ~2^-14 (fp16) / ~2^-11 (bf16) of its value — the per-element bounds tests/test_hip_mixed_pair.py
+ *                         asserts; a K = 768 product lands at ~1e-5 relative against 2e-4 with single operands),
  *                         the attention core takes 16-bit hi+lo pairs with three-term products — so prompt gradients match the
  *                         fp32 CPU path to 1e-3; forward-only towers (e.g. the image tower under CoOp, inference) stay fast.
  *                         Environment MVLPT_SPLIT_LO8=0 selects 16-bit hi+lo pairs for the GEMMs as well (twice the matrix time)

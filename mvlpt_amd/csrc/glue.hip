@@ -368,7 +368,11 @@ __global__ __launch_bounds__(1024) void reduce_prompt_rows_kernel(float* __restr
         *(f32x4*)(dx32 + o) = f32x4{0.f, 0.f, 0.f, 0.f};
         if (dx16) {
           typename Vec<T>::v4 z; for (int e = 0; e < 4; ++e) z[e] = (T)0.f;
-          if (split16) { *(typename Vec<T>::v4*)(dx16 + 2 * (o - c) + c) = z; *(typename Vec<T>::v4*)(dx16 + 2 * (o - c) + d + c) = z; }
+          T* row16 = dx16 + 2 * (o - c);                       // pair rows have a pitch of 2d elements
+          if (split16 == 2) {                                  // mixed pair [hi (d x 16 bit) | lo8 (d bytes) | unused]: the 4 residual bytes of columns c..c+3
+            *(typename Vec<T>::v4*)(row16 + c) = z;
+            *(uint32_t*)((char*)row16 + 2 * d + c) = 0u;
+          } else if (split16) { *(typename Vec<T>::v4*)(row16 + c) = z; *(typename Vec<T>::v4*)(row16 + d + c) = z; }
           else *(typename Vec<T>::v4*)(dx16 + o) = z;
         }
       }

@@ -40,7 +40,8 @@ struct GemmArgs {
   // A_lo8 = e5m2(A_lo * 2^Lo8<T>::EXP) (common.h), and Bt rows hold [W16 (K x 16 bit) | W8 (K bytes)] with pitch ldb >= 3K/2
   // elements, W8 = e4m3(W * 2^w8_exp): the product is A_hi*W16^T on v_mfma_f32_16x16x32 plus A_lo8*W8^T on
   // v_mfma_scale_f32_16x16x128_f8f6f4 (twice the rate, the e8m0 scale operands undo the two exponents) in the same
-  // accumulators: 1.5x the matrix time of a single-operand GEMM instead of 2x, the lo term carried at ~2^-16 of the value.
+  // accumulators: 1.5x the matrix time of a single-operand GEMM instead of 2x; the operand is carried to ~2^-14 (fp16) / ~2^-11
+  // (bf16) of its value (e5m2 residual x e4m3 weight copy; tests/test_hip_mixed_pair.py asserts these per-element bounds).
   // K % 128 == 0.
   int a_split = 0;
   int ldb = 0;         // Bt row pitch in 16-bit elements (0: K)
@@ -48,6 +49,9 @@ struct GemmArgs {
   int out_lo8 = 0;     // EPI_GELU_SPLIT / EPI_GELUBWD_SPLIT: store the pair as [hi | lo8] (mixed pair) instead of [hi | lo]
 #ifdef MVLPT_GEMM_TRACE
   long long* trace = nullptr;   // debug builds only: per-wave (point id << 56 | s_memtime) records of workgroup 0
+#endif
+#ifdef MVLPT_GEMM_STAGGER_EXP
+  int stagger = 0;              // experiment builds only: start delay (cycles) of every other group of 8 workgroups
 #endif
 };
 // ev_start/ev_stop (optional): recorded by the dispatch itself (hipExtLaunchKernelGGL): kernel-exact timing with no

@@ -58,10 +58,15 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
 
 
 class FlatGradients:
-    """ONE persistent fp32 buffer that every parameter's `.grad` is a view of (what DDP calls gradient_as_bucket_view).
-    Autograd accumulates into an existing `.grad` in place and `zero_grad(set_to_none=False)` zeroes in place, so the views
-    survive the training loop; the per-step exchange is then a single in-place collective on `flat` — no torch.cat, no
-    copy back, no scaling launch (RCCL averages itself: ReduceOp.AVG).  N > 1 adds exactly ONE launch per step."""
+    """ONE persistent fp32 buffer that the parameters' `.grad` are views of (what DDP calls gradient_as_bucket_view).
+    Autograd accumulates into an existing `.grad` in place and zeroing is one launch on the buffer, so the views survive the
+    training loop; the per-step exchange is then a single in-place collective on `flat` — no torch.cat, no copy back, no
+    scaling launch (RCCL averages itself: ReduceOp.AVG).  N > 1 adds exactly ONE launch per step.
+
+    A parameter's `.grad` is adopted (copied into its slot and replaced by the view) the first time it HAS one — at the first
+    exchange or `zero_()` after its first backward.  A parameter that never receives a gradient keeps `.grad is None`, exactly as
+    under Dassl's `optimizer.zero_grad()`, so SGD skips it (no weight decay / momentum drift on an unused prompt tensor,
+    checkpoints equal to the reference's); its slot in the buffer just stays zero."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
@@ -71,22 +76,27 @@ class FlatGradients:
         self.views: List[torch.Tensor] = []
         off = 0
         for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("FlatGradients: fp32 master parameters expected")
             v = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
             self.views.append(v)
         self.attach()
 
     def attach(self) -> None:
+        """Adopt every `.grad` that exists and is not yet its view."""
         for p, v in zip(self.params, self.views):
-            if p.dtype != torch.float32:
-                raise TypeError("FlatGradients: fp32 master parameters expected")
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
-            p.grad = v
+                p.grad = v
 
     def intact(self) -> bool:
-        """False once somebody replaced a `.grad` (zero_grad(set_to_none=True), a fresh tensor assigned by hand)."""
-        return all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
+        """False when a `.grad` exists that is not its view (a first backward, zero_grad(set_to_none=True) + backward, a
+        tensor assigned by hand): the next zero_() / all_reduce_mean_() adopts it."""
+        return all(p.grad is None or p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
+
+    def adopted(self) -> int:
+        return sum(1 for p, v in zip(self.params, self.views) if p.grad is not None and p.grad.data_ptr() == v.data_ptr())
 
     def zero_(self) -> None:
         if not self.intact():

@@ -111,6 +111,7 @@ class Engine:
         _lib.check(lib.mvlpt_set_precision(self.h, int(code)), self.h, "set_precision")
         self.precision = int(code)
 
+    @_on_device
     def trim(self) -> None:
         """Release workspace blocks that were outgrown (epoch boundary: synchronises the device)."""
         _lib.check(lib.mvlpt_trim(self.h), self.h, "trim")

@@ -206,11 +206,12 @@ class TrainerX:
 
     # -- loop
     def train(self):
+        """Dassl's generic loop: before_train / per epoch run_epoch + after_epoch / after_train."""
+        self.best_result = -math.inf
         for self.epoch in range(self.start_epoch, self.max_epoch):
             self.run_epoch()
             self.after_epoch()
-            if self.epoch + 1 == self.max_epoch:
-                self.save_model(self.epoch, self.output_dir)
+        self.after_train()
 
     def run_epoch(self):
         """One pass over train_loader_x: the plain Dassl loop — `for batch_idx, batch in
@@ -239,7 +240,26 @@ class TrainerX:
         return summary
 
     def after_epoch(self):
-        """Epoch boundary hook (Dassl's after_epoch): concrete trainers release what only a step needed."""
+        """Dassl's after_epoch (recalled from upstream): with TEST.FINAL_MODEL == "best_val" validate every
+        epoch and keep the best checkpoint as `model-best.pth.tar` — the file `load_model(directory, epoch=None)` opens
+        (trainers/mvlpt.py:1098-1104) —, and write `model.pth.tar-<epoch>` at the last epoch and every CHECKPOINT_FREQ epochs."""
+        last_epoch = (self.epoch + 1) == self.max_epoch
+        freq = self.cfg.TRAIN.CHECKPOINT_FREQ
+        if not self.cfg.TEST.NO_TEST and self.cfg.TEST.FINAL_MODEL == "best_val":
+            curr = self.test(split="val")
+            if curr > getattr(self, "best_result", -math.inf):
+                self.best_result = curr
+                self.save_model(self.epoch, self.output_dir, val_result=curr, model_name="model-best.pth.tar")
+        if last_epoch or (freq > 0 and (self.epoch + 1) % freq == 0):
+            self.save_model(self.epoch, self.output_dir)
+
+    def after_train(self):
+        """Dassl's after_train: final test, on the best-validation checkpoint when that is the model selection rule."""
+        if self.cfg.TEST.NO_TEST:
+            return None
+        if self.cfg.TEST.FINAL_MODEL == "best_val":
+            self.load_model(self.output_dir)
+        return self.test()
 
     def end_of_epoch_loop(self):
         """The loop left the loader (exhausted, hook break, exception): nothing of the look-ahead may survive it."""
@@ -450,6 +470,7 @@ class MVLPT(TrainerX):
             self.model.drop_prefetch()
 
     def after_epoch(self):
+        super().after_epoch()             # validation / checkpoints (Dassl)
         self.model.engine.trim()          # workspace blocks outgrown during the epoch (a larger eval batch, more classes)
 
     def parse_batch_train(self, batch):

@@ -44,17 +44,26 @@ def _worker(rank, world, port, ret):
     for p in params:
         p.grad = None
     fg = D.FlatGradients(params)
-    ptrs = [p.grad.data_ptr() for p in params]
-    for step in range(2):                        # two steps: the views must survive zero + backward
+    assert all(p.grad is None for p in params) and fg.intact() and fg.adopted() == 0    # nothing is adopted before it exists
+    ptrs = [v.data_ptr() for v in fg.views]
+    for step in range(3):                        # the first exchange adopts the fresh grads; the views then survive zero + backward
         fg.zero_()
         loss_fn(X[rank * 4:(rank + 1) * 4]).backward()
-        assert fg.intact() and [p.grad.data_ptr() for p in params] == ptrs
+        assert fg.intact() == (step > 0)
         fg.all_reduce_mean_(world)
+        assert fg.intact() and fg.adopted() == len(params) and [p.grad.data_ptr() for p in params] == ptrs
     flat_ok = all(torch.allclose(a, p.grad, rtol=1e-6, atol=1e-7) for a, p in zip(got, params))
     flat_ok = flat_ok and fg.flat.numel() == sum(p.numel() for p in params)
-    params[0].grad = None                        # somebody dropped a grad: re-attached at the next zero_()
+    params[0].grad = torch.ones_like(params[0])  # somebody replaced a grad: adopted again at the next zero_()
     fg.zero_()
-    flat_ok = flat_ok and fg.intact()
+    flat_ok = flat_ok and fg.intact() and params[0].grad.data_ptr() == ptrs[0] and float(params[0].grad.abs().sum()) == 0.0
+    # a parameter that never receives a gradient keeps .grad None (SGD skips it, as under Dassl's zero_grad): ADVICE r3
+    unused = torch.nn.Parameter(torch.ones(3))
+    fg2 = D.FlatGradients([params[3], unused])
+    fg2.zero_()
+    (params[3].sum() * 2).backward()
+    fg2.all_reduce_mean_(world)
+    flat_ok = flat_ok and unused.grad is None and fg2.adopted() == 1 and fg2.intact()
     for p in params:
         p.grad = None
     loss_fn(X).backward()                        # single-process reference on the concatenated batch

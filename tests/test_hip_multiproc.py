@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _build(method, csc):
+def _build(method, csc, device="cuda:0", names=NAMES):
     from mvlpt_amd.config import get_cfg_default
     from mvlpt_amd.model import CustomCLIP, FrozenCLIP
     from mvlpt_amd.weights import ARCHS, make_state_dict
@@ -36,19 +36,20 @@ def _build(method, csc):
         cfg.TRAINER.MVLPT.VPT.N_CTX = 2
     cfg.TRAINER.MVLPT.PROJECT_DIM = 64
     torch.manual_seed(7)
-    model = CustomCLIP(cfg, NAMES, FrozenCLIP(make_state_dict(arch, seed=5), "fp16", device="cuda:0")).to("cuda:0")
+    model = CustomCLIP(cfg, names, FrozenCLIP(make_state_dict(arch, seed=5), "fp16", device=device)).to(device)
     g = torch.Generator().manual_seed(11)
     image = torch.randn(8, 3, 32, 32, generator=g)
-    label = torch.randint(0, len(NAMES), (8,), generator=g)
+    label = torch.randint(0, len(names), (8,), generator=g)
     return model, image, label
 
 
 def _step(model, image, label):
     for p in model.parameters():
         p.grad = None
-    loss = model.cross_entropy(model(image.cuda()), label.cuda())
+    dev = next(model.parameters()).device
+    loss = model.cross_entropy(model(image.to(dev)), label.to(dev))
     loss.backward()
-    torch.cuda.synchronize()
+    torch.cuda.synchronize(dev)
     return {n: p.grad.detach().cpu().clone() for n, p in model.prompt_learner.named_parameters()}, float(loss.detach())
 
 

@@ -106,3 +106,46 @@ def test_our_checkpoint_loads_into_the_real_reference(tmp_path):
     assert not res.unexpected_keys and set(res.missing_keys) <= {"token_prefix", "token_suffix"}
     for n, p in ref_pl.named_parameters():
         assert torch.equal(p.detach(), tr.model.prompt_learner.state_dict()[n]), n
+
+
+def test_best_val_checkpoint_flow(tmp_path):
+    """Dassl's after_epoch / after_train with TEST.FINAL_MODEL = "best_val" (SURVEY Appendix B): validate every epoch, keep the
+    best as prompt_learner/model-best.pth.tar — the file `load_model(directory)` opens (trainers/mvlpt.py:1098-1104) —, write
+    model.pth.tar-<last epoch>, and run the final test on the best checkpoint."""
+    from tests.train_step_util import EpochLoader
+    z = load_npz("tiny_train_steps")
+    tr = _oracle_trainer(z)
+    tr.cfg.TEST.FINAL_MODEL, tr.cfg.TEST.NO_TEST, tr.cfg.DATASET.COOP = "best_val", False, True
+    tr.output_dir, tr.start_epoch, tr.dm = str(tmp_path), 0, None
+    batches = [{"img": t(z["images"][i]), "label": t(z["labels"][i]), "domain": torch.zeros(4, dtype=torch.long)} for i in range(3)]
+    tr.train_loader_x = EpochLoader(batches)
+    tr.val_loader, tr.test_loader = batches[:2], batches[2:]
+    seen = []
+    real_test = tr.test
+
+    def scripted_test(split=None):             # validation results 30, 50, 40: epoch 2 is the best
+        acc = real_test(split)
+        assert 0.0 <= acc <= 100.0
+        if split == "val":
+            seen.append([30.0, 50.0, 40.0][len(seen)])
+            return seen[-1]
+        return acc
+
+    tr.test = scripted_test
+    after = []
+    real_save = tr.save_model
+
+    def spy_save(epoch, directory, **kw):
+        after.append((epoch, kw.get("model_name", ""), {n: p.detach().clone() for n, p in tr.model.prompt_learner.named_parameters()}))
+        return real_save(epoch, directory, **kw)
+
+    tr.save_model = spy_save
+    tr.train()
+    d = tmp_path / "prompt_learner"
+    assert (d / "model-best.pth.tar").is_file() and (d / "model.pth.tar-3").is_file() and not (d / "model.pth.tar-1").exists()
+    best = torch.load(d / "model-best.pth.tar", map_location="cpu")
+    assert best["epoch"] == 2 and best["val_result"] == 50.0 and set(best) == {"state_dict", "epoch", "optimizer", "scheduler", "val_result"}
+    assert [(e, n) for e, n, _ in after] == [(0, "model-best.pth.tar"), (1, "model-best.pth.tar"), (2, "")]
+    # after_train loaded the best checkpoint (epoch 2's parameters, not the last epoch's) before the final test
+    for n, p in tr.model.prompt_learner.named_parameters():
+        assert torch.equal(p.detach(), after[1][2][n]), n

@@ -1,0 +1,9 @@
+#!/bin/bash
+# gpurun with retries while every GPU slot of the pod is busy (exit code 3 = nothing charged).  Usage: tools/gpurun_retry.sh <timeout> '<command>'
+T=$1; shift
+for i in $(seq 1 30); do
+  /usr/local/graft/bin/gpurun --timeout $T -- "$@"; rc=$?
+  [ $rc -ne 3 ] && exit $rc
+  sleep 60
+done
+exit 3
