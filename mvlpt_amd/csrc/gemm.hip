@@ -285,14 +285,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   [[maybe_unused]] const int e0 = ((2 * fg) ^ (fr & 7)) * 16, e1 = ((2 * fg + 1) ^ (fr & 7)) * 16;
   [[maybe_unused]] const int sc_w = 127 - g.w8_exp, sc_a = 127 - Lo8<T>::EXP;      // e8m0 scale bytes: undo the exponents of the two fp8 planes
 
-#ifdef MVLPT_GEMM_STAGGER_EXP
-  // experiment (tools/r04_stagger.sh): every other group of 8 workgroups starts g.stagger cycles late, so that the epilogue
-  // (HBM store burst) of one half of the chip falls into the main loop of the other half
-  if (g.stagger > 0 && ((b >> 3) & 1)) {
-    const long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < g.stagger) __builtin_amdgcn_s_sleep(8);
-  }
-#endif
   // prologue: fill NS-1 ring slots, wait for the first.  `n_issued` K-stages have been requested so far; a wait that
   // must guarantee stage j may leave the n_issued - (j + 1) younger stages in flight (vmcnt retires in order).
   int n_issued = 0, n_done = 0;
@@ -757,14 +749,7 @@ static hipError_t launch_epi(const GemmArgs& g, int epi, hipStream_t s, hipEvent
 }
 
 // K must be a multiple of 64 and N of 128 (every CLIP width is; conv K is zero-padded); M is arbitrary.
-hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g_in, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
-#ifdef MVLPT_GEMM_STAGGER_EXP
-  GemmArgs g = g_in;
-  static const int stag = getenv("MVLPT_GEMM_STAGGER") ? atoi(getenv("MVLPT_GEMM_STAGGER")) : 0;
-  g.stagger = stag;
-#else
-  const GemmArgs& g = g_in;
-#endif
+hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N % 128) != 0) return hipErrorInvalidValue;
   if (g.a_split == 2 && ((g.K % 128) != 0 || g.ldb < g.K + g.K / 2)) return hipErrorInvalidValue;
   if (g.ldb && (g.ldb < g.K || (g.ldb % 8) != 0)) return hipErrorInvalidValue;

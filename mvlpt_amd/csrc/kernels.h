@@ -50,9 +50,6 @@ struct GemmArgs {
 #ifdef MVLPT_GEMM_TRACE
   long long* trace = nullptr;   // debug builds only: per-wave (point id << 56 | s_memtime) records of workgroup 0
 #endif
-#ifdef MVLPT_GEMM_STAGGER_EXP
-  int stagger = 0;              // experiment builds only: start delay (cycles) of every other group of 8 workgroups
-#endif
 };
 // ev_start/ev_stop (optional): recorded by the dispatch itself (hipExtLaunchKernelGGL): kernel-exact timing with no
 // extra marker packets on the stream.

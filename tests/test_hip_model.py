@@ -191,6 +191,48 @@ def test_full_size_case_fp16(arch_name, name):
     print(f"{name}: logits {err:.2e} grads {max(worst.values()):.2e}")
 
 
+def _inference_logits(case, model, image):
+    """MVLPT.model_inference (trainers/mvlpt.py:986-987): eval mode, no_grad, `self.model(input, task=task)`."""
+    model.eval()
+    task = t(case["task"]) if "task" in case else None
+    with torch.no_grad():
+        return model(image.to(model.clip_model.device), task=task).cpu()
+
+
+def _check_inference(case, logits, name):
+    ref = t(case["out_logits"])
+    err = float((logits - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    assert err < TOL_FP16, f"{name}: inference logits err {err:.3e} (relative to max(1, max|ref|))"
+    assert torch.allclose(logits, ref, rtol=TOL_FP16, atol=TOL_FP16), f"{name}: inference logits element-wise allclose failed"
+
+
+@pytest.mark.parametrize("name", TINY_CASES)
+def test_inference_logits_match_reference_tiny(name, tiny_clip_fp16):
+    """The forward-only kernels behind `model_inference` (single 16-bit operands in the image tower, split operands in the text
+    tower, cached text features) against the reference's logits: the same 1e-3 bound as the training forward."""
+    case = load_npz(name)
+    model = build_model(case, tiny_clip_fp16, 32, t(case["token_prefix"]), t(case["token_suffix"]))
+    _check_inference(case, _inference_logits(case, model, t(case["image"])), name)
+    # a second call hits the per-parameter-version text-feature cache: same logits, bit for bit
+    assert torch.equal(_inference_logits(case, model, t(case["image"])), _inference_logits(case, model, t(case["image"])))
+
+
+@pytest.mark.parametrize("arch_name,name", FULL)
+def test_inference_logits_match_reference_full(arch_name, name):
+    from mvlpt_amd.model import FrozenCLIP
+    from mvlpt_amd.weights import ARCHS, make_state_dict
+    from tests.golden_util import full_case_inputs
+    if arch_name not in _full_clips:
+        _full_clips.clear()
+        sd = make_state_dict(ARCHS[arch_name], 2, include_token_embedding=True)
+        _full_clips[arch_name] = (FrozenCLIP(sd, compute_dtype="fp16"), sd)
+    clip, sd = _full_clips[arch_name]
+    case = load_npz(name)
+    res = ARCHS[arch_name].image_resolution
+    image, pre, suf = full_case_inputs(case, sd, res)
+    _check_inference(case, _inference_logits(case, build_model(case, clip, res, pre, suf), image), name)
+
+
 def test_trim_to_eot_is_exact(tiny_clip_fp16):
     """Evaluating the causal text tower only up to max(EOT) changes neither logits nor gradients (beyond fp rounding)."""
     case = load_npz("tiny_coop_middle")

@@ -345,6 +345,6 @@ def test_cfg5_vitl14_336_upt_1151_classes_batch_128():
         full = model(x)
         halves = torch.cat([model(x[:64].contiguous()), model(x[64:].contiguous())])
     assert torch.equal(halves, full)
-    # (the inference forward keeps single 16-bit operands through 24 layers of 581 tokens: measured 1.1e-3 of max|logit| against the
-    # split-operand training forward, which itself sits 3e-5 from the reference (full_vitl14_336 fixture); PREC = "fp32" removes it)
-    assert float((full - l0).abs().max()) <= 2e-3 * float(l0.abs().max()), "training and inference forwards agree to 2e-3"
+    # (the inference forward keeps single 16-bit operands in the image tower — 24 layers of 581 tokens —, the text tower runs with
+    # split operands in both; the training forward sits 3e-5 from the reference (full_vitl14_336 fixture))
+    assert float((full - l0).abs().max()) <= 1e-3 * float(l0.abs().max()), "training and inference forwards agree to 1e-3"
