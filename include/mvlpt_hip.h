@@ -56,6 +56,12 @@ enum { MVLPT_PREC_FAST = 0, MVLPT_PREC_SPLIT_GRAD = 1, MVLPT_PREC_SPLIT_ALL = 2 
 int mvlpt_create(const MvlptArch* arch, void** handle);
 /* switch the precision mode (takes effect at the next tower forward) */
 int mvlpt_set_precision(void* handle, int mode);
+/* LayerNorm folding (no counterpart in the reference, which calls nn.LayerNorm as its own op, clip/model.py:186-187): inside a
+ * tower the GEMM in front of a LayerNorm (out-projection / MLP down-projection + fp32 residual) also writes round16(x * gamma)
+ * and per-row partial sums, and the GEMM behind it (QKV / MLP up-projection) applies mean and rstd in its epilogue — the
+ * stand-alone LayerNorm pass over the residual stream disappears.  mode 0: off, 1: image tower, 2: both towers (default;
+ * environment MVLPT_LN_FOLD); towers with fewer than `min_rows` token rows (default 4096) keep the stand-alone kernel. */
+int mvlpt_set_ln_fold(void* handle, int mode, int min_rows);
 /* Workspaces only grow, and a block that was outgrown is retired (not freed) so that no step ever meets a device-wide sync.
  * mvlpt_trim synchronises the device and releases the retired blocks: call it at an epoch boundary (e.g. after a one-off large
  * evaluation batch or class list). */
@@ -157,6 +163,20 @@ int mvlpt_op_pack_weight_mixed(int dtype, const float* w32, int rows, int cols, 
 int mvlpt_op_gemm_mixed(int dtype, int epi, const void* A, const void* Bt, int ldb, int w8_exp, int M, int N, int K, const float* bias,
                         const void* aux, const float* resid, void* out, void* out2, mvlpt_stream_t stream);
 int mvlpt_op_cast_mixed(int dtype, const float* in, void* out, int64_t rows, int d, mvlpt_stream_t stream);
+/* ---- LayerNorm folding at kernel level (see mvlpt_set_ln_fold): LN(x) W^T + b = rstd_r (x gamma) W^T - rstd_r mean_r (W gamma) + (b + W beta).
+ * fold_vectors: colsum = W gamma, bias2 = b + W beta from the PACKED 16-bit weight W16 [N, ld] (load time).
+ * gemm_ln_producer: out32 = A Bt^T + bias + resid (as epilogue 2) AND x16 = round16(out32 * gamma) in the A-operand format
+ *   x16_split (0 [M,N], 1 hi|lo pair [M,2N], 2 mixed pair) AND part[(row * ntp + tile) * 2 ..] = {sum, sum of squares} of the row over
+ *   each of the *nt N-tiles of the launch (ntp: slots per row, even, >= *nt, <= 6).  A: a_split 0 / 1 / 2 as in op_gemm*.
+ * gemm_folded: epilogue `epi` (0, 1, 5, 7) on A16 = x16 with the normalisation applied from `part` (K = length of the rows). */
+int mvlpt_op_fold_vectors(int dtype, const void* W16, int ld, const float* gamma, const float* beta, const float* b, float* colsum,
+                          float* bias2, int N, int K, mvlpt_stream_t stream);
+int mvlpt_op_gemm_ln_producer(int dtype, const void* A, int a_split, const void* Bt, int ldb, int w8_exp, int M, int N, int K,
+                              const float* bias, const float* resid, const float* gamma, int x16_split, float* out32, void* x16,
+                              float* part, int ntp, int* nt, mvlpt_stream_t stream);
+int mvlpt_op_gemm_folded(int dtype, int epi, const void* A16, int a_split, const void* Bt, int ldb, int w8_exp, int M, int N, int K,
+                         const float* colsum, const float* bias2, const float* part, int ntp, int nt, void* out, void* out2,
+                         mvlpt_stream_t stream);
 int mvlpt_op_layernorm_fwd_mixed(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
                                  mvlpt_stream_t stream);
 int mvlpt_op_layernorm_bwd_mixed(int dtype, const void* dy, const float* x, const float* gamma, const float* resid, float* out32,

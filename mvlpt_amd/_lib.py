@@ -47,6 +47,7 @@ SIGNATURES = {
     "mvlpt_destroy": (_i, [_vp]),
     "mvlpt_set_precision": (_i, [_vp, _i]),
     "mvlpt_trim": (_i, [_vp]),
+    "mvlpt_set_ln_fold": (_i, [_vp, _i, _i]),
     "mvlpt_last_error": (C.c_char_p, [_vp]),
     "mvlpt_version": (C.c_char_p, []),
     "mvlpt_stream_create_cus": (_i, [_i, _i, C.POINTER(_vp)]),
@@ -70,6 +71,9 @@ SIGNATURES = {
     "mvlpt_op_pack_weight_mixed": (_i, [_i, _vp, _i, _i, _i, _vp, C.POINTER(C.c_int), _vp]),
     "mvlpt_op_gemm_mixed": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvlpt_op_cast_mixed": (_i, [_i, _vp, _vp, C.c_int64, _i, _vp]),
+    "mvlpt_op_fold_vectors": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mvlpt_op_gemm_ln_producer": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, C.POINTER(C.c_int), _vp]),
+    "mvlpt_op_gemm_folded": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "mvlpt_op_layernorm_fwd_mixed": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mvlpt_op_layernorm_bwd_mixed": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mvlpt_op_attention32_fwd_mixed": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -106,6 +106,7 @@ struct WRef { const void* p; int ld; int e8; };
 struct Linear {
   void* w = nullptr; void* wt = nullptr; float* b = nullptr; int out = 0, in = 0;
   int ldw = 0, ldwt = 0, e8 = 0;
+  float *fold_s = nullptr, *fold_b = nullptr;   // LayerNorm folding: W gamma and b + W beta of the LayerNorm in front (qkv: ln_1, fc: ln_2)
   WRef fw() const { return WRef{w, ldw, e8}; }      // forward Bt operand  [out, in]
   WRef bw() const { return WRef{wt, ldwt, e8}; }    // dX Bt operand       [in, out]
 };
@@ -125,7 +126,13 @@ struct TowerState {
   float* dx32 = nullptr; void *dx16 = nullptr, *du16 = nullptr, *dO16 = nullptr, *dqkv16 = nullptr; float* dh32 = nullptr;
   float* delta = nullptr; float* scale_dev = nullptr;
   std::vector<char> skip;                // layer skipped (reference deep-prompt quirk, Appendix A.3)
+  // LayerNorm folding (kernels.h): per-row, per-N-tile {sum, sum of squares} of the residual stream in front of ln_1 / ln_2,
+  // written by the FC2 / out-projection epilogues; h16 then holds round16(x * gamma) instead of LN(x)
+  bool fold = false;
+  float* part[2] = {nullptr, nullptr};   // [T][FOLD_NTP][2]
+  int nt[2] = {0, 0}, ntp[2] = {0, 0};   // slots in use / slots per row, as the last producer wrote them
 };
+constexpr int FOLD_NTP = 6;              // slots per row the buffers are sized for (gemm.hip: FOLD_MAX_NTP)
 
 enum ProfClass { PC_GEMM = 0, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD, PC_GLUE, PC_HEAD, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm_bt", "attention_fwd", "attention_bwd", "layernorm_fwd", "layernorm_bwd",
@@ -136,6 +143,9 @@ struct Engine {
   MvlptArch arch{};
   int dt = DT_F16;
   int prec_mode = MVLPT_PREC_SPLIT_GRAD;
+  int fold_mode = 2;    // LayerNorm folding: 0 off, 1 image tower, 2 both towers (MVLPT_LN_FOLD, mvlpt_set_ln_fold)
+  int fold_min_rows = 4096;   // towers with fewer token rows keep the stand-alone LayerNorm (a handful of tiles: nothing to win)
+  bool fold_ready = false;
   bool lo8 = true;      // split towers of MVLPT_PREC_SPLIT_GRAD use the mixed pair (hi + e5m2 residual byte; MVLPT_SPLIT_LO8=0: 16-bit pairs)
   std::string err;
   TowerW vis, txt;
@@ -191,13 +201,22 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------------------------------------ kernel wrappers
+// LayerNorm folding of one GEMM call (GemmArgs::ln_* / fold_*)
+struct Fold {
+  const float* ln_gamma = nullptr; void* ln_x16 = nullptr; int ln_split = 0; float* ln_part = nullptr; int ln_ntp = 0;   // producer
+  const float* fold_part = nullptr; const float* fold_colsum = nullptr; int fold_ntp = 0, fold_nt = 0;                   // consumer
+};
 hipError_t gemm(Engine* E, int epi, const void* A, WRef Bt, int M, int N, int K, const float* bias, const void* aux,
-                const float* resid, void* out, void* out2, hipStream_t s, int dtype = -1, int a_split = 0) {
+                const float* resid, void* out, void* out2, hipStream_t s, int dtype = -1, int a_split = 0, const Fold* f = nullptr) {
   GemmArgs g{A, Bt.p, M, N, K, bias, aux, resid, out, out2};
   g.a_split = a_split; g.ldb = Bt.ld; g.w8_exp = Bt.e8;
+  if (f) {
+    g.ln_gamma = f->ln_gamma; g.ln_x16 = f->ln_x16; g.ln_split = f->ln_split; g.ln_part = f->ln_part; g.ln_ntp = f->ln_ntp;
+    g.fold_part = f->fold_part; g.fold_colsum = f->fold_colsum; g.fold_ntp = f->fold_ntp; g.fold_nt = f->fold_nt;
+  }
   g.out_lo8 = (a_split == 2 && (epi == EPI_GELU_SPLIT || epi == EPI_GELUBWD_SPLIT)) ? 1 : 0;
   const int dt = dtype >= 0 ? dtype : E->dt;
-  const double ob = (epi == EPI_RESID32) ? 8.0 : ((epi == EPI_STORE32 || epi == EPI_STORE_SPLIT) ? 4.0 : ((epi == EPI_GELUBWD || epi == EPI_GELU_SPLIT) ? 4.0 :
+  const double ob = (epi == EPI_RESID32) ? 8.0 : (epi == EPI_RESID32_LN) ? 8.0 + 2.0 * (a_split ? 1.5 : 1.0) : ((epi == EPI_STORE32 || epi == EPI_STORE_SPLIT) ? 4.0 : ((epi == EPI_GELUBWD || epi == EPI_GELU_SPLIT) ? 4.0 :
                     (epi == EPI_GELUBWD_SPLIT ? 6.0 : 2.0)));
   // the dominant kernel is timed by its own dispatch (start/stop timestamps of the AQL packet): no marker packets
   hipEvent_t ea = nullptr, eb = nullptr;
@@ -243,6 +262,7 @@ size_t tower_bytes(const TowerW& W, int N, int L, bool save, bool exact) {
   b += (save ? nl : 1) * align256((size_t)N * H * L * 4);            // lse
   b += (save ? nl : 1) * align256(T * 4 * d * 2);                    // u
   b += align256(T * 4 * d * 2 * X);                                  // a16
+  b += 2 * align256(T * FOLD_NTP * 8);                               // LayerNorm-folding partials
   if (save) {
     b += 2 * align256(T * d * 4) + 2 * align256(T * d * 2 * X) + (align256(T * 4 * d * 2) + align256(T * 3 * d * 2)) * X;
     b += align256((size_t)N * H * L * 4) + 256;
@@ -266,6 +286,7 @@ void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool s
     st.u[l] = fresh ? bp.take_bytes(T * 4 * d * 2) : st.u[0];
   }
   st.a16 = bp.take_bytes(T * 4 * d * 2 * X);
+  st.part[0] = bp.take<float>(T * FOLD_NTP * 2); st.part[1] = bp.take<float>(T * FOLD_NTP * 2);
   if (save) {
     st.dx32 = bp.take<float>(T * d);
     st.dx16 = bp.take_bytes(T * d * 2 * X); st.dh32 = bp.take<float>(T * d); st.dO16 = bp.take_bytes(T * d * 2 * X);
@@ -297,19 +318,51 @@ int attn32_bwd(Engine* E, TowerState& st, int l, hipStream_t s) {
   return 0;
 }
 
+// ---- LayerNorm folding (kernels.h GemmArgs::ln_* / fold_*): the residual GEMM in front of a LayerNorm writes
+// round16(x * gamma) into h16 and per-row partial sums; the GEMM behind it applies mean / rstd in its epilogue.
+// which = 0: the LayerNorm is ln_1 (producer: FC2 of the previous block), 1: ln_2 (producer: this block's out-projection).
+bool fold_producer(Engine* E, TowerState& st, int which, int M, int N, int K, const LNp& ln, hipStream_t s, Fold* f) {
+  if (!st.fold) return false;
+  GemmArgs q{};
+  q.M = M; q.N = N; q.K = K; q.a_split = st.xs;
+  const int bn = gemm_tile_n(E->dt, EPI_RESID32_LN, q, s);      // the launcher's N-tile for this problem on this stream
+  if (bn <= 0 || N % bn) return false;
+  const int nt = N / bn, ntp = (nt + 1) & ~1;
+  if (ntp > FOLD_NTP) return false;
+  *f = Fold();
+  f->ln_gamma = ln.g; f->ln_x16 = st.h16; f->ln_split = st.xs; f->ln_part = st.part[which]; f->ln_ntp = ntp;
+  st.nt[which] = nt; st.ntp[which] = ntp;
+  return true;
+}
+Fold fold_consumer(const TowerState& st, int which, const Linear& L) {
+  Fold f;
+  f.fold_part = st.part[which]; f.fold_colsum = L.fold_s; f.fold_ntp = st.ntp[which]; f.fold_nt = st.nt[which];
+  return f;
+}
+
 // Split-precision variant of block_fwd / block_bwd below: every GEMM A operand is a 16-bit hi|lo pair (~22 bits), the
 // attention core runs in fp32.  Used for towers that carry a gradient (and for every tower under MVLPT_PREC_SPLIT_ALL).
-int block_fwd_x(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
+// ln1_folded: h16 / part[0] already hold this block's ln_1 input in folded form (written by the previous block's FC2);
+// next_ln1: the LayerNorm the block's output goes into next, when that one may be folded; *produced: it was.
+int block_fwd_x(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s, bool ln1_folded, const LNp* next_ln1, bool* produced) {
   const Block& B = W.blocks[l];
   const int T = st.N * st.L, d = st.d;
   float* xin = st.x[2 * l]; float* xmid = st.x[2 * l + 1]; float* xout = st.x[2 * l + 2];
-  HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, B.ln1, st.h16, T, d, s, st.xs));
-  HIPCHK(E, gemm(E, EPI_STORE_SPLIT, st.h16, B.qkv.fw(), T, 3 * d, d, B.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, st.xs));
+  Fold fq, fo, ff, fp;
+  if (ln1_folded) fq = fold_consumer(st, 0, B.qkv);
+  else HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, B.ln1, st.h16, T, d, s, st.xs));
+  HIPCHK(E, gemm(E, EPI_STORE_SPLIT, st.h16, B.qkv.fw(), T, 3 * d, d, ln1_folded ? B.qkv.fold_b : B.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, st.xs,
+                 ln1_folded ? &fq : nullptr));
   if (int rc = attn32_fwd(E, st, l, 0, s)) return rc;
-  HIPCHK(E, gemm(E, EPI_RESID32, st.attn[l], B.o.fw(), T, d, d, B.o.b, nullptr, xin, xmid, nullptr, s, -1, st.xs));
-  HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, B.ln2, st.h16, T, d, s, st.xs));
-  HIPCHK(E, gemm(E, EPI_GELU_SPLIT, st.h16, B.fc.fw(), T, 4 * d, d, B.fc.b, nullptr, nullptr, st.a16, st.saved ? st.u[l] : nullptr, s, -1, st.xs));
-  HIPCHK(E, gemm(E, EPI_RESID32, st.a16, B.pr.fw(), T, d, 4 * d, B.pr.b, nullptr, xmid, xout, nullptr, s, -1, st.xs));
+  const bool p2 = fold_producer(E, st, 1, T, d, d, B.ln2, s, &fo);
+  HIPCHK(E, gemm(E, p2 ? EPI_RESID32_LN : EPI_RESID32, st.attn[l], B.o.fw(), T, d, d, B.o.b, nullptr, xin, xmid, nullptr, s, -1, st.xs, p2 ? &fo : nullptr));
+  if (p2) ff = fold_consumer(st, 1, B.fc);
+  else HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, B.ln2, st.h16, T, d, s, st.xs));
+  HIPCHK(E, gemm(E, EPI_GELU_SPLIT, st.h16, B.fc.fw(), T, 4 * d, d, p2 ? B.fc.fold_b : B.fc.b, nullptr, nullptr, st.a16, st.saved ? st.u[l] : nullptr, s, -1, st.xs,
+                 p2 ? &ff : nullptr));
+  const bool p1 = next_ln1 && fold_producer(E, st, 0, T, d, 4 * d, *next_ln1, s, &fp);
+  HIPCHK(E, gemm(E, p1 ? EPI_RESID32_LN : EPI_RESID32, st.a16, B.pr.fw(), T, d, 4 * d, B.pr.b, nullptr, xmid, xout, nullptr, s, -1, st.xs, p1 ? &fp : nullptr));
+  if (produced) *produced = p1;
   return 0;
 }
 int block_bwd_x(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
@@ -325,24 +378,34 @@ int block_bwd_x(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s
   return 0;
 }
 
-// ResidualAttentionBlock.forward (clip/model.py:185-188) on token buffers
-int block_fwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
-  if (st.exact) return block_fwd_x(E, W, st, l, s);
+// ResidualAttentionBlock.forward (clip/model.py:185-188) on token buffers (LayerNorm folding: see block_fwd_x)
+int block_fwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s, bool ln1_folded = false, const LNp* next_ln1 = nullptr,
+              bool* produced = nullptr) {
+  if (produced) *produced = false;
+  if (st.exact) return block_fwd_x(E, W, st, l, s, ln1_folded, next_ln1, produced);
   const Block& B = W.blocks[l];
   const int T = st.N * st.L, d = st.d;
   float* xin = st.x[2 * l]; float* xmid = st.x[2 * l + 1]; float* xout = st.x[2 * l + 2];
-  HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, B.ln1, st.h16, T, d, s));
-  HIPCHK(E, gemm(E, EPI_STORE16, st.h16, B.qkv.fw(), T, 3 * d, d, B.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s));
+  Fold fq, fo, ff, fp;
+  if (ln1_folded) fq = fold_consumer(st, 0, B.qkv);
+  else HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, B.ln1, st.h16, T, d, s));
+  HIPCHK(E, gemm(E, EPI_STORE16, st.h16, B.qkv.fw(), T, 3 * d, d, ln1_folded ? B.qkv.fold_b : B.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, 0,
+                 ln1_folded ? &fq : nullptr));
   {
     AttnArgs a{st.qkv[l], st.attn[l], st.saved ? st.lse[l] : nullptr, st.N, st.L, st.H, st.causal ? 1 : 0};
     const double fl = 4.0 * st.L * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0);
     ProfScope ps(E, s, PC_ATTN_FWD, fl, (double)T * d * 2.0 * 4.0);
     HIPCHK(E, launch_attn_fwd(E->dt, a, s));
   }
-  HIPCHK(E, gemm(E, EPI_RESID32, st.attn[l], B.o.fw(), T, d, d, B.o.b, nullptr, xin, xmid, nullptr, s));
-  HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, B.ln2, st.h16, T, d, s));
-  HIPCHK(E, gemm(E, EPI_GELU, st.h16, B.fc.fw(), T, 4 * d, d, B.fc.b, nullptr, nullptr, st.a16, st.saved ? st.u[l] : nullptr, s));
-  HIPCHK(E, gemm(E, EPI_RESID32, st.a16, B.pr.fw(), T, d, 4 * d, B.pr.b, nullptr, xmid, xout, nullptr, s));
+  const bool p2 = fold_producer(E, st, 1, T, d, d, B.ln2, s, &fo);
+  HIPCHK(E, gemm(E, p2 ? EPI_RESID32_LN : EPI_RESID32, st.attn[l], B.o.fw(), T, d, d, B.o.b, nullptr, xin, xmid, nullptr, s, -1, 0, p2 ? &fo : nullptr));
+  if (p2) ff = fold_consumer(st, 1, B.fc);
+  else HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, B.ln2, st.h16, T, d, s));
+  HIPCHK(E, gemm(E, EPI_GELU, st.h16, B.fc.fw(), T, 4 * d, d, p2 ? B.fc.fold_b : B.fc.b, nullptr, nullptr, st.a16, st.saved ? st.u[l] : nullptr, s, -1, 0,
+                 p2 ? &ff : nullptr));
+  const bool p1 = next_ln1 && fold_producer(E, st, 0, T, d, 4 * d, *next_ln1, s, &fp);
+  HIPCHK(E, gemm(E, p1 ? EPI_RESID32_LN : EPI_RESID32, st.a16, B.pr.fw(), T, d, 4 * d, B.pr.b, nullptr, xmid, xout, nullptr, s, -1, 0, p1 ? &fp : nullptr));
+  if (produced) *produced = p1;
   return 0;
 }
 
@@ -455,6 +518,28 @@ const char* first_missing(Engine* E) {
   return m.empty() ? nullptr : m.c_str();
 }
 
+// LayerNorm folding: the per-column vectors of every linear layer that follows a LayerNorm (qkv <- ln_1, fc <- ln_2), once,
+// when all frozen tensors are there (the first tower forward)
+int prepare_fold(Engine* E, hipStream_t s) {
+  if (E->fold_ready) return 0;
+  for (TowerW* W : {&E->vis, &E->txt}) {
+    const int d = W->width;
+    for (Block& B : W->blocks) {
+      for (int k = 0; k < 2; ++k) {
+        Linear& L = k ? B.fc : B.qkv;
+        const LNp& ln = k ? B.ln2 : B.ln1;
+        void* p = nullptr;
+        HIPCHK(E, hipMalloc(&p, (size_t)L.out * 2 * sizeof(float)));
+        E->owned.push_back(p);
+        L.fold_s = (float*)p; L.fold_b = (float*)p + L.out;
+        HIPCHK(E, launch_fold_vectors(E->dt, L.w, L.ldw, ln.g, ln.b, L.b, L.fold_s, L.fold_b, L.out, d, s));
+      }
+    }
+  }
+  E->fold_ready = true;
+  return 0;
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -482,6 +567,8 @@ int mvlpt_create(const MvlptArch* a, void** handle) {
   Engine* E = new Engine();
   E->arch = *a; E->dt = a->compute_dtype;
   if (const char* v = getenv("MVLPT_SPLIT_LO8")) E->lo8 = atoi(v) != 0;
+  if (const char* v = getenv("MVLPT_LN_FOLD")) E->fold_mode = atoi(v);
+  if (const char* v = getenv("MVLPT_LN_FOLD_MIN_ROWS")) E->fold_min_rows = atoi(v) > 0 ? atoi(v) : 1;
   E->vis.width = a->vision_width; E->vis.layers = a->vision_layers; E->vis.heads = a->vision_heads;
   E->vis.blocks.resize(a->vision_layers);
   E->txt.width = a->text_width; E->txt.layers = a->text_layers; E->txt.heads = a->text_heads;
@@ -531,6 +618,14 @@ int mvlpt_stream_destroy(mvlpt_stream_t stream) {
 }
 
 int mvlpt_stream_cus(mvlpt_stream_t stream) { return stream_cus((hipStream_t)stream); }
+
+int mvlpt_set_ln_fold(void* h, int mode, int min_rows) {
+  Engine* E = (Engine*)h;
+  if (!E) return MVLPT_ERR_ARG;
+  if (mode < 0 || mode > 2 || min_rows < 1) return fail(E, MVLPT_ERR_ARG, "set_ln_fold: mode in {0, 1, 2}, min_rows >= 1");
+  E->fold_mode = mode; E->fold_min_rows = min_rows;
+  return 0;
+}
 
 int mvlpt_trim(void* h) {
   Engine* E = (Engine*)h;
@@ -665,6 +760,8 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   carve_tower(bp, E->vis, E->vs, B, Lv, save, false, exact, split_kind(E));
   TowerState& st = E->vs;
   E->vB = B; E->v_nvpt = n_vpt; E->v_ndeep = n_deep;
+  st.fold = E->fold_mode >= 1 && (size_t)B * Lv >= (size_t)E->fold_min_rows && dv >= 256;
+  if (st.fold) if (int rc = prepare_fold(E, s)) return rc;
 
   { ProfScope ps(E, s, PC_GLUE, 0, (double)npatch * E->Kp * 6.0);
     HIPCHK(E, launch_patchify(E->dt, image, image_dtype, patches, B, A.image_resolution, A.patch_size, E->Kp, s)); }
@@ -672,6 +769,15 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   { ProfScope ps(E, s, PC_GLUE, 0, (double)B * Lv * dv * 8.0);
     HIPCHK(E, launch_assemble_tokens(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, vpt, n_vpt, st.x[0], B, G2, dv, s)); }
   bool cls_only_last = false;
+  bool ln1_ready = false;       // LayerNorm folding: the previous block's FC2 left this block's ln_1 input in folded form
+  // ln_1 of block l can be folded when nothing touches the residual stream between FC2 of block l-1 and it: not behind a
+  // deep-prompt overwrite, not behind a skipped block
+  auto next_foldable = [&](int l) -> const LNp* {
+    const int n = l + 1;
+    if (!st.fold || n >= E->vis.layers) return nullptr;
+    if (n_deep > 0) return nullptr;                       // rows 1..n_vpt are overwritten (or the block is skipped) in front of every later ln_1
+    return &E->vis.blocks[n].ln1;
+  };
   for (int l = 0; l < E->vis.layers; ++l) {
     if (l > 0 && n_deep > 0) {
       if (l <= n_deep) {
@@ -687,7 +793,9 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
       }
     }
     if (l == E->vis.layers - 1) { cls_only_last = true; break; }
-    if (int rc = block_fwd(E, E->vis, st, l, s)) return rc;
+    bool produced = false;
+    if (int rc = block_fwd(E, E->vis, st, l, s, ln1_ready, next_foldable(l), &produced)) return rc;
+    ln1_ready = produced;
   }
   if (cls_only_last) {
     // Only x[:, 0, :] of the last block is consumed (trainers/mvlpt.py:88): keys/values are still needed for every
@@ -702,8 +810,11 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
     float* xout = save ? E->xco32 : E->xc32;     // ... and ln_post input
     E->v_cls_last = save;
     const int xs = st.xs;                 // split-precision operands (hi|lo pairs, twice the columns) + pair-product attention
-    HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dv, s, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, st.h16, Bk.qkv.fw(), T, 3 * dv, dv, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
+    Fold fq;
+    if (ln1_ready) fq = fold_consumer(st, 0, Bk.qkv);
+    else HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dv, s, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, st.h16, Bk.qkv.fw(), T, 3 * dv, dv, ln1_ready ? Bk.qkv.fold_b : Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs,
+                   ln1_ready ? &fq : nullptr));
     if (xs) {
       // only the CLS rows of the attention output are produced: the backward (delta = rowsum(dO * O) over EVERY row, with
       // dO = 0 off the CLS rows) must not meet uninitialised memory there
@@ -839,12 +950,18 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
   carve_tower(bp, E->txt, E->ts, C, L, save, true, exact, split_kind(E));
   TowerState& st = E->ts;
   E->tC = C; E->tL = L; E->t_nctx = n_ctx; E->t_per_class = ctx_per_class;
+  st.fold = E->fold_mode >= 2 && (size_t)C * L >= (size_t)E->fold_min_rows && dtw >= 256;
+  if (st.fold) if (int rc = prepare_fold(E, s)) return rc;
   { ProfScope ps(E, s, PC_GLUE, 0, (double)C * L * dtw * 12.0);
     HIPCHK(E, launch_assemble_prompts(prefix, suffix, ctx, ctx_per_class, n_ctx, layout, E->tpos, st.x[0], C, L, dtw, s));
     HIPCHK(E, launch_eot_rows(eot, E->eot_rows, C, L, s));
     if (save && n_ctx > 0) HIPCHK(E, launch_build_ctx_pos(layout, E->ctx_pos, C, L, n_ctx, s)); }
-  for (int l = 0; l + 1 < E->txt.layers; ++l)
-    if (int rc = block_fwd(E, E->txt, st, l, s)) return rc;
+  bool ln1_ready = false;
+  for (int l = 0; l + 1 < E->txt.layers; ++l) {
+    bool produced = false;
+    if (int rc = block_fwd(E, E->txt, st, l, s, ln1_ready, st.fold ? &E->txt.blocks[l + 1].ln1 : nullptr, &produced)) return rc;
+    ln1_ready = produced;
+  }
   {
     // Only x[c, eot_c] of the last block is consumed (trainers/mvlpt.py:126-128): LN1, QKV and the attention run for every
     // position (keys / values), then out-proj, ln_2, the MLP and ln_final run on the C gathered EOT rows — forward and,
@@ -855,8 +972,11 @@ int mvlpt_text_fwd(void* h, const float* prefix, const float* suffix, const floa
     float* xin = st.x[2 * l];
     E->t_eot_last = save;
     const int xs = st.xs;
-    HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dtw, s, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, st.h16, Bk.qkv.fw(), T, 3 * dtw, dtw, Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs));
+    Fold fq;
+    if (ln1_ready) fq = fold_consumer(st, 0, Bk.qkv);
+    else HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dtw, s, xs));
+    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, st.h16, Bk.qkv.fw(), T, 3 * dtw, dtw, ln1_ready ? Bk.qkv.fold_b : Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs,
+                   ln1_ready ? &fq : nullptr));
     if (xs) {
       if (int rc = attn32_fwd(E, st, l, 0, s)) return rc;
     } else {
@@ -1037,6 +1157,34 @@ int mvlpt_op_gemm_mixed(int dtype, int epi, const void* A, const void* Bt, int l
   GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
   g.a_split = 2; g.ldb = ldb; g.w8_exp = w8_exp;
   g.out_lo8 = (epi == EPI_GELU_SPLIT || epi == EPI_GELUBWD_SPLIT) ? 1 : 0;
+  OPCHK(launch_gemm(dtype, epi, g, (hipStream_t)stream));
+  return 0;
+}
+// ---- LayerNorm folding, kernel level (the same launches block_fwd makes)
+int mvlpt_op_fold_vectors(int dtype, const void* W16, int ld, const float* gamma, const float* beta, const float* b, float* colsum,
+                          float* bias2, int N, int K, mvlpt_stream_t stream) {
+  OPCHK(launch_fold_vectors(dtype, W16, ld, gamma, beta, b, colsum, bias2, N, K, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_gemm_ln_producer(int dtype, const void* A, int a_split, const void* Bt, int ldb, int w8_exp, int M, int N, int K,
+                              const float* bias, const float* resid, const float* gamma, int x16_split, float* out32, void* x16,
+                              float* part, int ntp, int* nt, mvlpt_stream_t stream) {
+  GemmArgs g{A, Bt, M, N, K, bias, nullptr, resid, out32, nullptr};
+  g.a_split = a_split; g.ldb = ldb; g.w8_exp = w8_exp;
+  g.ln_gamma = gamma; g.ln_x16 = x16; g.ln_split = x16_split; g.ln_part = part; g.ln_ntp = ntp;
+  const int bn = gemm_tile_n(dtype, EPI_RESID32_LN, g, (hipStream_t)stream);
+  if (bn <= 0 || N % bn || N / bn > ntp) { g_create_err = "gemm_ln_producer: ntp smaller than the number of N-tiles of this launch"; return MVLPT_ERR_ARG; }
+  if (nt) *nt = N / bn;
+  OPCHK(launch_gemm(dtype, EPI_RESID32_LN, g, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_gemm_folded(int dtype, int epi, const void* A16, int a_split, const void* Bt, int ldb, int w8_exp, int M, int N, int K,
+                         const float* colsum, const float* bias2, const float* part, int ntp, int nt, void* out, void* out2,
+                         mvlpt_stream_t stream) {
+  GemmArgs g{A16, Bt, M, N, K, bias2, nullptr, nullptr, out, out2};
+  g.a_split = a_split; g.ldb = ldb; g.w8_exp = w8_exp;
+  g.out_lo8 = (a_split == 2 && epi == EPI_GELU_SPLIT) ? 1 : 0;
+  g.fold_part = part; g.fold_colsum = colsum; g.fold_ntp = ntp; g.fold_nt = nt;
   OPCHK(launch_gemm(dtype, epi, g, (hipStream_t)stream));
   return 0;
 }

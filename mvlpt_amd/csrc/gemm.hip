@@ -70,17 +70,88 @@ struct SlabRows {
   }
 };
 
-template <typename T, int EPI, typename Rows16, typename Rows32>
+// LayerNorm folding (kernels.h): the 16 KiB LDS region behind the ring.  Consumer: the partial sums of the tile's rows,
+// [row][ntp] float2, copied there by LDS-DMA with the tile's last K-stage.  Producer: [row][wave column] float2 of this tile.
+constexpr int XLDS_BYTES = 16384;
+constexpr int XLDS_COLSUM = 12288, XLDS_BIAS = 13312;   // consumer: the tile's colsum / bias slices (<= 256 floats each) behind <= 12 KiB of partials
+constexpr int XLDS_COEF = 14336;                         // consumer: {rstd, -rstd * mean} of the tile's rows (256 x 8 B), written once per tile
+constexpr int FOLD_MAX_NTP = 6;                          // 256 rows x 6 slots x 8 B = 12 KiB
+constexpr float FOLD_LN_EPS = 1e-5f;      // = LN_EPS of norm.hip (clip/model.py:153-159)
+struct FoldCtx {
+  char* xl;      // the region
+  int mrel;      // first row of this wave's 64x64 block inside the tile
+  int wn, wcn;   // column block of the wave / number of column blocks (producer)
+  int xs;        // producer: format of the 16-bit copy (GemmArgs::ln_split; a compile-time 2 in the mixed-pair kernels)
+};
+// {rstd, -rstd * mean} of tile row `row_rel`: the table fold_build_coef left behind the partials
+__device__ __forceinline__ void fold_row_coef(const GemmArgs&, const char* xl, int row_rel, float& a, float& cc) {
+  const float2 q = *(const float2*)(xl + XLDS_COEF + row_rel * 8);
+  a = q.x; cc = q.y;
+}
+// ... built once per tile (thread r = tile row r) from the row's partial sums, summed in slot order: deterministic
+__device__ __forceinline__ void fold_build_coef(const GemmArgs& g, char* xl, int row_rel) {
+  float a, cc;
+  const f32x4* p = (const f32x4*)(xl + (size_t)row_rel * g.fold_ntp * 8);
+  float s1 = 0.f, s2 = 0.f;
+  for (int t2 = 0; 2 * t2 < g.fold_nt; ++t2) {
+    const f32x4 q = p[t2];
+    s1 += q[0]; s2 += q[1];
+    if (2 * t2 + 1 < g.fold_nt) { s1 += q[2]; s2 += q[3]; }
+  }
+  const float inv_d = 1.0f / (float)g.K;
+  const float mean = s1 * inv_d;
+  const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
+  a = rsqrtf(var + FOLD_LN_EPS);
+  cc = -a * mean;
+  *(float2*)(xl + XLDS_COEF + row_rel * 8) = float2{a, cc};
+}
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: quad butterflies, then the two mirrors.
+// VALU only (ds_bpermute-based shuffles would put ~8 LDS round trips into every row segment of the epilogue)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+// 16-bit copy of four values in the A-operand formats of kernels.h (0 single, 1 hi|lo pair, 2 mixed pair); `base` [M, N or 2N]
+template <typename T>
+__device__ __forceinline__ void store_a16(void* base, int split, size_t m, int N, int col, f32x4 v) {
+  using v4 = typename Vec<T>::v4;
+  if (split == 0) {
+    v4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(v[e]);
+    *(v4*)((T*)base + m * N + col) = w;
+  } else if (split == 1) {
+    v4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { T h, l; split16<T>(v[e], h, l); hi[e] = h; lo[e] = l; }
+    T* row = (T*)base + m * (2 * (size_t)N);
+    *(v4*)(row + col) = hi;
+    *(v4*)(row + N + col) = lo;
+  } else {
+    v4 hi;
+    const uint32_t lo8 = split_lo8x4<T>(v, hi);
+    T* row = (T*)base + m * (2 * (size_t)N);
+    *(v4*)(row + col) = hi;
+    *(uint32_t*)((char*)row + 2 * (size_t)N + col) = lo8;
+  }
+}
+
+template <typename T, int EPI_, typename Rows16, typename Rows32>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&acc)[4][4], int mbase, int nbase, int lane,
-                                               Rows16 rows16, Rows32 rows32) {
+                                               Rows16 rows16, Rows32 rows32, FoldCtx fc) {
   using v4 = typename Vec<T>::v4;
   using v8 = typename Vec<T>::v8;
   const int M = g.M, N = g.N;      // N % 128 == 0 (checked at launch): no column guard
   const int fr = lane & 15, fg = lane >> 4;
+  constexpr int EPI = epi_base(EPI_);
+  constexpr bool fold = epi_folds(EPI_);     // consumer side of the LayerNorm folding compiled in
   f32x4 bv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (g.bias) {
+  if (g.bias && EPI != EPI_RESID32_LN && !fold) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + nbase + j * 16 + fg * 4);
   }
@@ -93,16 +164,41 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
       if (which == 1 && !outp) break;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
+        if constexpr (fold) {
+          // the tile's colsum / bias slices sit in LDS (ds_read: no vmcnt, nothing to keep in registers across the stores).
+          // All LDS reads of the half first (two rows' partials, four column-vector pairs), then the arithmetic: read-then-use
+          // per (row, column block) would expose one LDS round trip 32 times per tile
+          float fa[2], fcc[2];
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          const int i = half * 2 + ii;
+          for (int ii = 0; ii < 2; ++ii) fold_row_coef(g, fc.xl, fc.mrel + (half * 2 + ii) * 16 + fr, fa[ii], fcc[ii]);
+          f32x4 sj[4], bj[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const f32x4 v = acc[i][j] + bv[j];
-            v4 w;
+            sj[j] = *(const f32x4*)(fc.xl + XLDS_COLSUM + (fc.wn * 64 + j * 16 + fg * 4) * 4);
+            bj[j] = *(const f32x4*)(fc.xl + XLDS_BIAS + (fc.wn * 64 + j * 16 + fg * 4) * 4);
+          }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = from_f32<T>((EPI == EPI_GELU && which == 0) ? quick_gelu(v[e]) : v[e]);
-            *(v4*)(rows16(ii * 16 + fr) + (j * 16 + fg * 4) * 2) = w;
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x4 v = fa[ii] * acc[half * 2 + ii][j] + (fcc[ii] * sj[j] + bj[j]);
+              v4 w;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) w[e] = from_f32<T>((EPI == EPI_GELU && which == 0) ? quick_gelu(v[e]) : v[e]);
+              *(v4*)(rows16(ii * 16 + fr) + (j * 16 + fg * 4) * 2) = w;
+            }
+        } else {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const int i = half * 2 + ii;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x4 v = acc[i][j] + bv[j];
+              v4 w;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) w[e] = from_f32<T>((EPI == EPI_GELU && which == 0) ? quick_gelu(v[e]) : v[e]);
+              *(v4*)(rows16(ii * 16 + fr) + (j * 16 + fg * 4) * 2) = w;
+            }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -117,26 +213,42 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
       }
     }
   } else {
-    const int c = lane & 15, rq = lane >> 4;                  // 16 lanes x 16 B = one 256-B row segment (fp32)
+    int c = lane & 15, rq = lane >> 4;                        // 16 lanes x 16 B = one 256-B row segment (fp32)
+    // opaque to loop-invariant code motion: hipcc otherwise hoists the per-(pass, row) address offsets of this epilogue (resid,
+    // out, the 16-bit copy: up to ~48 values) out of the persistent tile loop and keeps — or spills — them around the main loop
+    // (EPI_RESID32_LN at 256x256: 30 spilled VGPRs without this, 239 VGPRs and none with it)
+    asm volatile("" : "+v"(c), "+v"(rq));
+    constexpr bool RESID = EPI == EPI_RESID32 || EPI == EPI_RESID32_LN;
     // Every global LOAD of the epilogue is issued before its first store: hipcc waits vmcnt(0) on an ordinary
     // load while LDS-DMA is in flight, and that wait would also drain the stores issued before it.
     f32x4 rv[4][4];
     v4 uv[4][4];
-    if constexpr (EPI == EPI_RESID32 || EPI == EPI_GELUBWD || EPI == EPI_GELUBWD_SPLIT) {
+    if constexpr (RESID || EPI == EPI_GELUBWD || EPI == EPI_GELUBWD_SPLIT) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           int m = mbase + i * 16 + it * 4 + rq;
           m = m < M ? m : M - 1;
-          if constexpr (EPI == EPI_RESID32) rv[i][it] = __builtin_nontemporal_load((const f32x4*)(g.resid + (size_t)m * N + nbase + c * 4));
+          if constexpr (RESID) rv[i][it] = __builtin_nontemporal_load((const f32x4*)(g.resid + (size_t)m * N + nbase + c * 4));
           else uv[i][it] = __builtin_nontemporal_load((const v4*)((const T*)g.aux + (size_t)m * N + nbase + c * 4));
         }
     }
+    // after the transpose a lane owns the SAME four columns nbase + 4c .. + 3 in every pass: per-column vectors cost 4 registers
+    [[maybe_unused]] f32x4 colb = {0.f, 0.f, 0.f, 0.f}, cols = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == EPI_RESID32_LN) {
+      if (g.bias) colb = *(const f32x4*)(g.bias + nbase + c * 4);
+      cols = *(const f32x4*)(g.ln_gamma + nbase + c * 4);
+    }
+    if constexpr (fold) {      // the bias is added behind the row scale: the raw accumulators are staged
+      colb = *(const f32x4*)(fc.xl + XLDS_BIAS + (fc.wn * 64 + c * 4) * 4);
+      cols = *(const f32x4*)(fc.xl + XLDS_COLSUM + (fc.wn * 64 + c * 4) * 4);
+    }
+    constexpr bool stage_raw = fold || EPI == EPI_RESID32_LN;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *(f32x4*)(rows32(fr) + (j * 16 + fg * 4) * 4) = acc[i][j] + bv[j];
+      for (int j = 0; j < 4; ++j) *(f32x4*)(rows32(fr) + (j * 16 + fg * 4) * 4) = stage_raw ? acc[i][j] : acc[i][j] + bv[j];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -144,9 +256,26 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
         f32x4 v = *(const f32x4*)(rows32(r) + c * 16);
         const int m = mbase + i * 16 + r;
         const size_t o = (size_t)m * N + nbase + c * 4;
+        if constexpr (fold) {
+          float fa, fcc;
+          fold_row_coef(g, fc.xl, fc.mrel + i * 16 + r, fa, fcc);
+          v = fa * v + (fcc * cols + colb);
+        }
         if constexpr (EPI == EPI_RESID32) {
           v += rv[i][it];
           if (m < M) __builtin_nontemporal_store(v, (f32x4*)((float*)g.out + o));
+        } else if constexpr (EPI == EPI_RESID32_LN) {
+          v += rv[i][it] + colb;
+          // partial sums of the row over this wave's 64 columns: the 16 lanes of a row segment hold them
+          float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+          float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          s1 = row16_sum(s1); s2 = row16_sum(s2);
+          if (c == 0) *(float2*)(fc.xl + ((size_t)(fc.mrel + i * 16 + r) * fc.wcn + fc.wn) * 8) = float2{s1, s2};
+          if (m < M) {
+            __builtin_nontemporal_store(v, (f32x4*)((float*)g.out + o));
+            store_a16<T>(g.ln_x16, fc.xs, (size_t)m, N, nbase + c * 4, v * cols);
+          }
+          __builtin_amdgcn_sched_barrier(0);     // one row segment at a time: interleaved passes cost registers this kernel does not have
         } else if constexpr (EPI == EPI_GELUBWD) {
           v4 w;
 #pragma unroll
@@ -197,7 +326,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   constexpr int WMF = BM_ / WCM / 16;                 // 16-row A fragments per wave (4: 64x64 wave tile, 8: 128x64)
   constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int A_IT = BM_ / 8 / NW, B_IT = BN / 8 / NW, LOADS = A_IT + B_IT;
-  constexpr int ST_MIN_ = (WMF / 4) * ((EPI == EPI_STORE16 || EPI == EPI_GELU) ? 8 : 16);
+  constexpr int ST_MIN_ = (WMF / 4) * ((epi_base(EPI) == EPI_STORE16 || epi_base(EPI) == EPI_GELU) ? 8 : 16);
+  constexpr bool CAN_FOLD = epi_folds(EPI);
+  [[maybe_unused]] char* const xlds = smem + NS * STAGE;        // LayerNorm folding: XLDS_BYTES behind the ring (when launched with them)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -265,6 +396,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
     const int bk = ((lkt >= nkb && !mixed) ? lkt - nkb : lkt) * BK;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) glds16(bp[i] + bk, base + A_BYTES + (i * NW + wave) * 1024);
+    if constexpr (CAN_FOLD) {
+      // LayerNorm folding: the {sum, sum of squares} partials of this tile's rows, [row][ntp] float2 = one contiguous block
+      // of the global array, copied behind the ring with the tile's LAST K-stage: issued after the barrier that ends the
+      // previous tile's epilogue (nk >= NS), landed — like the stage itself — before this tile's epilogue
+      if (lkt == nk - 1) {
+        const int cpr = g.fold_ntp >> 1;                       // 16-byte chunks per row
+        const long first = (long)(lt / tilesN) * BM_ * cpr, last = (long)M * cpr - 1;
+        for (int q0 = wave * 64; q0 < BM_ * cpr; q0 += NW * 64) {
+          long q = first + q0 + lane; q = q < last ? q : last;
+          glds16(g.fold_part + q * 4, xlds + q0 * 16);
+        }
+        // ... and the tile's slices of W gamma and b + W beta (BN floats each: the epilogue reads them with ds_read)
+        const int n0 = (lt % tilesN) * BN + (lane < BN / 4 ? lane : BN / 4 - 1) * 4;
+        if (wave == NW - 1) glds16(g.fold_colsum + n0, xlds + XLDS_COLSUM);
+        if (wave == NW - 2) glds16(g.bias + n0, xlds + XLDS_BIAS);
+      }
+    }
     lslot = lslot + 1 == NS ? 0 : lslot + 1;
     if (++lkt == nk) {
       lkt = 0;
@@ -439,13 +587,35 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
     // and fence the scratch reads of all waves against that DMA with one more barrier
     int tm, tn;
     tile_mn(t, tm, tn);
+    if constexpr (CAN_FOLD) {
+      // LayerNorm folding: the rows' {rstd, -rstd * mean} once per tile (the partials landed with the last K-stage), then one
+      // barrier; the epilogue reads 8 bytes per row instead of re-deriving them in every lane
+      if (tid < BM_) fold_build_coef(g, xlds, tid);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
 #pragma unroll
     for (int hh = 0; hh < WMF / 4; ++hh)
       epilogue_store<T, EPI>(g, acc[hh], tm * BM_ + wm * (WMF * 16) + hh * 64, tn * BN + wn * 64, lane,
                              LinearRows<144>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE},
-                             LinearRows<272>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE});
+                             LinearRows<272>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE},
+                             FoldCtx{xlds, wm * (WMF * 16) + hh * 64, wn, WCN, MIXED ? 2 : (g.ln_split ? 1 : 0)});
     MVLPT_TR(9);
     __builtin_amdgcn_s_barrier();
+    if constexpr (EPI == EPI_RESID32_LN) {
+      // the tile's row partials: the WCN column blocks summed in a fixed order, one 8-byte slot per (row, N-tile); the region is
+      // rewritten by the next tile's epilogue, nk barriers from here
+      if (tid < BM_) {
+        const int row = tm * BM_ + tid;
+        if (row < M) {
+          const float2* p = (const float2*)(xlds + (size_t)tid * WCN * 8);
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < WCN; ++w) { s1 += p[w].x; s2 += p[w].y; }
+          *(float2*)(g.ln_part + ((size_t)row * g.ln_ntp + tn) * 2) = float2{s1, s2};
+        }
+      }
+    }
     stores_pending = (tm + 1) * BM_ <= M;
   }
 }
@@ -595,7 +765,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_phased_kernel(GemmArgs g) {
     }
     const int tm = t / tilesN, tn = t - tm * tilesN;
     epilogue_store<T, EPI>(g, acc, tm * BM_ + wm * 64, tn * BN + wn * 64, lane,
-                           SlabRows<144>{smem + lslot * STAGE, wave, A_BYTES}, SlabRows<272>{smem + lslot * STAGE, wave, A_BYTES});
+                           SlabRows<144>{smem + lslot * STAGE, wave, A_BYTES}, SlabRows<272>{smem + lslot * STAGE, wave, A_BYTES},
+                           FoldCtx{nullptr, 0, 0, 0, 0});     // (launch_one never sends a folded GEMM here)
     stores_pending = (tm + 1) * BM_ <= M;
   }
   if (!trail) __builtin_amdgcn_s_barrier();         // balance the extra barrier of the trailing group
@@ -620,23 +791,26 @@ static hipError_t launch_geo_m(const GemmArgs& g, int wg_per_cu, hipStream_t s, 
   constexpr int LDS = NS * (BM_ + BN_) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + XLDS_BYTES);
     attr_set = true;
   }
+  // LayerNorm folding: 16 KiB behind the ring (the consumer's row partials / the producer's per-tile column-block sums)
+  const int lds = LDS + ((epi_folds(EPI) || EPI == EPI_RESID32_LN) ? XLDS_BYTES : 0);
   int cus = stream_cus(s);
 #ifdef MVLPT_DEBUG_CUS
   if (getenv("MVLPT_DBG_CUS")) cus = atoi(getenv("MVLPT_DBG_CUS"));      // CU-scaling measurement, debug builds only
 #endif
   const int tiles = ((g.M + BM_ - 1) / BM_) * ((g.N + BN_ - 1) / BN_);
   const int resident = cus * wg_per_cu;
-  hipExtLaunchKernelGGL((gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), LDS, s,
+  hipExtLaunchKernelGGL((gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), lds, s,
                         ea, eb, 0, g);
   return hipGetLastError();
 }
 template <typename T, int EPI, int BM_, int BN_, int NW, int NS>
 static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
   // the mixed pair only exists with the epilogues a split tower uses (fp32 outputs and the pair-producing ones)
-  if constexpr (EPI == EPI_RESID32 || EPI == EPI_STORE32 || EPI == EPI_GELU_SPLIT || EPI == EPI_GELUBWD_SPLIT || EPI == EPI_STORE_SPLIT) {
+  constexpr int BE = epi_base(EPI);
+  if constexpr (BE == EPI_RESID32 || BE == EPI_RESID32_LN || BE == EPI_STORE32 || BE == EPI_GELU_SPLIT || BE == EPI_GELUBWD_SPLIT || BE == EPI_STORE_SPLIT) {
     if (g.a_split == 2) return launch_geo_m<T, EPI, BM_, BN_, NW, NS, true>(g, wg_per_cu, s, ea, eb);
   } else if (g.a_split == 2) return hipErrorInvalidValue;
   return launch_geo_m<T, EPI, BM_, BN_, NW, NS, false>(g, wg_per_cu, s, ea, eb);
@@ -648,7 +822,8 @@ template <int EPI>
 static GemmArgs row_slice(const GemmArgs& g, int m_lo, int rows) {
   GemmArgs r = g;
   const size_t ok = (size_t)m_lo * g.K * (g.a_split ? 2 : 1), on = (size_t)m_lo * g.N;
-  constexpr size_t OB = (EPI == EPI_RESID32 || EPI == EPI_STORE32 || EPI == EPI_GELU_SPLIT || EPI == EPI_GELUBWD_SPLIT || EPI == EPI_STORE_SPLIT) ? 4 : 2;
+  constexpr int BE = epi_base(EPI);
+  constexpr size_t OB = (BE == EPI_RESID32 || BE == EPI_RESID32_LN || BE == EPI_STORE32 || BE == EPI_GELU_SPLIT || BE == EPI_GELUBWD_SPLIT || BE == EPI_STORE_SPLIT) ? 4 : 2;
   r.A = (const char*)g.A + ok * 2;
   r.M = rows;
   r.out = (char*)g.out + on * OB;
@@ -677,9 +852,11 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   const bool big = g.N % 256 == 0 && (t256 >= 4 * cus || (t256 >= 2 * cus && Keff >= 2048));
   const bool r15 = 2 * t128 >= 3 * cus;      // >= 1.5 rounds of 256x128 tiles
   // (the phased kernel has no fp8 stages: mixed pairs take the plain 256x128 geometry)
-  if (g.a_split != 2 && r15 && (phased == 1 || (phased == 2 && Keff >= 2048 && !big))) {
+  // (nor the LayerNorm-folding fields: folded GEMMs take the plain geometries)
+  constexpr bool folded = epi_folds(EPI) || EPI == EPI_RESID32_LN;
+  if (g.a_split != 2 && !folded && r15 && (phased == 1 || (phased == 2 && Keff >= 2048 && !big))) {
     *tile_m = 256; *tile_n = 128;
-    return ea == (hipEvent_t)-1 ? hipSuccess : launch_phased<T, EPI>(g, s, ea, eb);
+    if constexpr (!folded) return ea == (hipEvent_t)-1 ? hipSuccess : launch_phased<T, EPI>(g, s, ea, eb);
   }
   if (geo >= 2 && big) {
     *tile_m = 256; *tile_n = 256;
@@ -735,6 +912,15 @@ static hipError_t launch_t(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipE
 
 template <typename T>
 static hipError_t launch_epi(const GemmArgs& g, int epi, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  if (g.fold_part) {
+    switch (epi) {
+      case EPI_STORE16: return launch_t<T, EPI_STORE16_FOLD>(g, s, ea, eb);
+      case EPI_GELU: return launch_t<T, EPI_GELU_FOLD>(g, s, ea, eb);
+      case EPI_STORE_SPLIT: return launch_t<T, EPI_STORE_SPLIT_FOLD>(g, s, ea, eb);
+      case EPI_GELU_SPLIT: return launch_t<T, EPI_GELU_SPLIT_FOLD>(g, s, ea, eb);
+    }
+    return hipErrorInvalidValue;
+  }
   switch (epi) {
     case EPI_STORE16: return launch_t<T, EPI_STORE16>(g, s, ea, eb);
     case EPI_GELU: return launch_t<T, EPI_GELU>(g, s, ea, eb);
@@ -744,8 +930,22 @@ static hipError_t launch_epi(const GemmArgs& g, int epi, hipStream_t s, hipEvent
     case EPI_GELU_SPLIT: return launch_t<T, EPI_GELU_SPLIT>(g, s, ea, eb);
     case EPI_GELUBWD_SPLIT: return launch_t<T, EPI_GELUBWD_SPLIT>(g, s, ea, eb);
     case EPI_STORE_SPLIT: return launch_t<T, EPI_STORE_SPLIT>(g, s, ea, eb);
+    case EPI_RESID32_LN: return launch_t<T, EPI_RESID32_LN>(g, s, ea, eb);
   }
   return hipErrorInvalidValue;
+}
+
+template <typename T>
+static int tile_n_epi(const GemmArgs& g, int epi, hipStream_t s) {
+  int bm = 0, bn = 0;
+  switch (epi) {      // (the geometry does not depend on the epilogue except for the phased routing, which folded GEMMs skip)
+    case EPI_RESID32_LN: (void)launch_one<T, EPI_RESID32_LN>(g, s, (hipEvent_t)-1, nullptr, &bm, &bn); break;
+    default: (void)launch_one<T, EPI_RESID32>(g, s, (hipEvent_t)-1, nullptr, &bm, &bn); break;
+  }
+  return bn;
+}
+int gemm_tile_n(int dtype, int epi, const GemmArgs& g, hipStream_t s) {
+  return dtype == DT_BF16 ? tile_n_epi<bf16>(g, epi, s) : tile_n_epi<f16>(g, epi, s);
 }
 
 // K must be a multiple of 64 and N of 128 (every CLIP width is; conv K is zero-padded); M is arbitrary.
@@ -753,7 +953,15 @@ hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hip
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N % 128) != 0) return hipErrorInvalidValue;
   if (g.a_split == 2 && ((g.K % 128) != 0 || g.ldb < g.K + g.K / 2)) return hipErrorInvalidValue;
   if (g.ldb && (g.ldb < g.K || (g.ldb % 8) != 0)) return hipErrorInvalidValue;
-  if (epi == EPI_RESID32 && !g.resid) return hipErrorInvalidValue;
+  if ((epi == EPI_RESID32 || epi == EPI_RESID32_LN) && !g.resid) return hipErrorInvalidValue;
+  if (epi == EPI_RESID32_LN && (!g.ln_gamma || !g.ln_x16 || !g.ln_part || g.ln_ntp <= 0 || (g.ln_ntp & 1))) return hipErrorInvalidValue;
+  if (g.fold_part) {
+    const bool can = epi == EPI_STORE16 || epi == EPI_GELU || epi == EPI_STORE_SPLIT || epi == EPI_GELU_SPLIT;
+    const int nk = g.a_split == 2 ? g.K / BK + g.K / 128 : (g.a_split ? 2 : 1) * (g.K / BK);
+    // the row partials ride with the LAST K-stage of a tile: it must be issued inside the tile's own K loop (ring depth <= 4)
+    if (!can || !g.fold_colsum || !g.bias || g.fold_nt <= 0 || g.fold_nt > g.fold_ntp || g.fold_ntp > FOLD_MAX_NTP || (g.fold_ntp & 1) || nk < 4)
+      return hipErrorInvalidValue;
+  }
   if ((epi == EPI_GELUBWD || epi == EPI_GELUBWD_SPLIT) && !g.aux) return hipErrorInvalidValue;
   if (dtype == DT_F16) return launch_epi<f16>(g, epi, s, ea, eb);
   if (dtype == DT_BF16) return launch_epi<bf16>(g, epi, s, ea, eb);

@@ -551,6 +551,35 @@ hipError_t launch_grad_scale(const float* v, size_t n, float target, float* scal
   return hipGetLastError();
 }
 
+// LayerNorm folding (kernels.h, GemmArgs::fold_*): the two per-column vectors of a linear layer that follows a LayerNorm,
+// colsum[n] = sum_k W[n,k] gamma[k] and bias2[n] = b[n] + sum_k W[n,k] beta[k], from the packed 16-bit weight (exactly the values
+// the MFMA multiplies).  One wave per output column, fp32, fixed summation order.  Load time only.
+template <typename T>
+__global__ __launch_bounds__(256) void fold_vectors_kernel(const T* __restrict__ W, int ld, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ b,
+                                                           float* __restrict__ colsum, float* __restrict__ bias2, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const T* w = W + (size_t)n * ld;
+  float sg = 0.f, sb = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float x = to_f32<T>(w[k]);
+    sg += x * gamma[k];
+    sb += x * beta[k];
+  }
+  sg = wave_sum(sg); sb = wave_sum(sb);
+  if (lane == 0) { colsum[n] = sg; bias2[n] = (b ? b[n] : 0.f) + sb; }
+}
+hipError_t launch_fold_vectors(int dtype, const void* W16, int ld, const float* gamma, const float* beta, const float* b,
+                               float* colsum, float* bias2, int N, int K, hipStream_t s) {
+  if (N <= 0 || K <= 0) return hipErrorInvalidValue;
+  if (dtype == DT_F16) hipLaunchKernelGGL(fold_vectors_kernel<f16>, dim3((N + 3) / 4), dim3(256), 0, s, (const f16*)W16, ld, gamma, beta, b, colsum, bias2, N, K);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(fold_vectors_kernel<bf16>, dim3((N + 3) / 4), dim3(256), 0, s, (const bf16*)W16, ld, gamma, beta, b, colsum, bias2, N, K);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ head (fp32)
 // xn = x / ||x||  (no epsilon: trainers/mvlpt.py:550-551)
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ xn,

@@ -22,7 +22,17 @@ enum GemmEpi {
   EPI_GELU_SPLIT = 5,     // u = acc+bias ; out2 (optional, 16-bit [M,N]) = u ; out [M,2N] = split(QuickGELU(u))
   EPI_GELUBWD_SPLIT = 6,  // out [M,2N] = split(acc * QuickGELU'(aux16))
   EPI_STORE_SPLIT = 7,    // out [M,2N] = split(acc (+bias))
+  // EPI_RESID32 that also PRODUCES the input of the LayerNorm behind it in folded form (GemmArgs::ln_*, "LayerNorm folding")
+  EPI_RESID32_LN = 8,
+  // internal: EPI_STORE16 / EPI_GELU / EPI_STORE_SPLIT / EPI_GELU_SPLIT with the consumer side of the folding compiled in
+  // (launch_gemm selects them when GemmArgs::fold_part is set; callers pass the plain values)
+  EPI_STORE16_FOLD = 9, EPI_GELU_FOLD = 10, EPI_STORE_SPLIT_FOLD = 11, EPI_GELU_SPLIT_FOLD = 12,
 };
+constexpr int epi_base(int epi) {
+  return epi == EPI_STORE16_FOLD ? EPI_STORE16 : epi == EPI_GELU_FOLD ? EPI_GELU : epi == EPI_STORE_SPLIT_FOLD ? EPI_STORE_SPLIT
+         : epi == EPI_GELU_SPLIT_FOLD ? EPI_GELU_SPLIT : epi;
+}
+constexpr bool epi_folds(int epi) { return epi >= EPI_STORE16_FOLD && epi <= EPI_GELU_SPLIT_FOLD; }
 struct GemmArgs {
   const void* A;       // [M,K] 16-bit
   const void* Bt;      // [N,K] 16-bit
@@ -47,10 +57,31 @@ struct GemmArgs {
   int ldb = 0;         // Bt row pitch in 16-bit elements (0: K)
   int w8_exp = 0;      // a_split == 2: exponent of the weight's fp8 plane
   int out_lo8 = 0;     // EPI_GELU_SPLIT / EPI_GELUBWD_SPLIT: store the pair as [hi | lo8] (mixed pair) instead of [hi | lo]
+  // ---- LayerNorm folding: LN(x) W^T = rstd_r * ((x * gamma) W^T)[r,n] - rstd_r * mean_r * (W gamma)[n] + (W beta)[n], so the
+  // GEMM in front of a LayerNorm hands the un-normalised row to the GEMM behind it and the LayerNorm pass (one read of the fp32
+  // residual stream + one 16-bit write per LayerNorm) disappears.  No atomics, no extra launch: every output tile owns its slots.
+  // Producer (EPI_RESID32_LN): besides out32 = acc + bias + resid32 the epilogue stores ln_x16 = round16(out32 * ln_gamma) — the A
+  // operand of the consumer, format ln_split: 0 [M,N], 1 hi|lo pair [M,2N], 2 mixed pair (same pitch) — and, per row and N-tile
+  // tn, the partial sums {sum out32, sum out32^2} over the tile's columns at ln_part[(row * ln_ntp + tn) * 2] (fp32 pairs).
+  const float* ln_gamma = nullptr;
+  void* ln_x16 = nullptr;
+  int ln_split = 0;
+  float* ln_part = nullptr;
+  int ln_ntp = 0;               // slots per row (>= number of N-tiles of this launch, even)
+  // Consumer (EPI_STORE16 / EPI_GELU / EPI_STORE_SPLIT / EPI_GELU_SPLIT with fold_part != null): A holds round16(x * gamma);
+  // mean / rstd of row r are rebuilt from its fold_nt partials (summed in slot order: deterministic) and the epilogue computes
+  // rstd_r * acc - rstd_r * mean_r * fold_colsum[n] + bias[n], with fold_colsum = W gamma and bias = b + W beta precomputed
+  // (frozen weights).  K is the length of the normalised rows.  The partials of a tile's rows ride along with its last K-stage
+  // (LDS-DMA into a 16 KiB region behind the ring), so the epilogue reads them from LDS.
+  const float* fold_part = nullptr;
+  const float* fold_colsum = nullptr;
+  int fold_ntp = 0, fold_nt = 0;
 #ifdef MVLPT_GEMM_TRACE
   long long* trace = nullptr;   // debug builds only: per-wave (point id << 56 | s_memtime) records of workgroup 0
 #endif
 };
+// N-tile width the launcher picks for this problem on this stream (the producer's partial-slot count is N / it)
+int gemm_tile_n(int dtype, int epi, const GemmArgs& g, hipStream_t s);
 // ev_start/ev_stop (optional): recorded by the dispatch itself (hipExtLaunchKernelGGL): kernel-exact timing with no
 // extra marker packets on the stream.
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hipEvent_t ev_start = nullptr,
@@ -185,6 +216,9 @@ hipError_t launch_gather_ctx_grad(const float* dx, const int32_t* ctx_pos, int C
 // scale_dev[0] = 2^k with amax(|v|)*2^k ~ target ; scale_dev[1] = 1/scale_dev[0]
 hipError_t launch_grad_scale(const float* v, size_t n, float target, float* scale_dev, hipStream_t s);
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);
+// LayerNorm folding: colsum[n] = sum_k W16[n,k] gamma[k], bias2[n] = b[n] + sum_k W16[n,k] beta[k]  (W16 [N, ld] packed weight)
+hipError_t launch_fold_vectors(int dtype, const void* W16, int ld, const float* gamma, const float* beta, const float* b,
+                               float* colsum, float* bias2, int N, int K, hipStream_t s);
 
 // ---------------------------------------------------------------- head: cosine logits + cross-entropy (fp32)
 hipError_t launch_normalize_rows(const float* x, float* xn, float* norm, int rows, int d, hipStream_t s);

@@ -111,6 +111,10 @@ class Engine:
         _lib.check(lib.mvlpt_set_precision(self.h, int(code)), self.h, "set_precision")
         self.precision = int(code)
 
+    def set_ln_fold(self, mode: int, min_rows: int = 4096) -> None:
+        """LayerNorm folding (include/mvlpt_hip.h: mvlpt_set_ln_fold): 0 off, 1 image tower, 2 both towers."""
+        _lib.check(lib.mvlpt_set_ln_fold(self.h, int(mode), int(min_rows)), self.h, "set_ln_fold")
+
     @_on_device
     def trim(self) -> None:
         """Release workspace blocks that were outgrown (epoch boundary: synchronises the device)."""
@@ -488,3 +492,43 @@ def op_attention_bwd(qkv, out, dout, lse, N, L, H, causal):
     _lib.check(lib.mvlpt_op_attention_bwd(_TORCH2DT[qkv.dtype], _ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(delta),
                                           _ptr(dqkv), N, L, H, int(causal), _stream()), None, "op_attention_bwd")
     return dqkv
+
+
+# ---- LayerNorm folding at kernel level (include/mvlpt_hip.h: mvlpt_op_fold_vectors / gemm_ln_producer / gemm_folded)
+def op_fold_vectors(W16: torch.Tensor, K: int, gamma, beta, b):
+    """W16: packed 16-bit weight [N, ld >= K] -> (colsum = W gamma, bias2 = b + W beta), fp32 [N]."""
+    N, ld = W16.shape
+    cs = torch.empty(N, device=W16.device, dtype=torch.float32)
+    b2 = torch.empty(N, device=W16.device, dtype=torch.float32)
+    _lib.check(lib.mvlpt_op_fold_vectors(_TORCH2DT[W16.dtype], _ptr(W16), ld, _ptr(gamma), _ptr(beta), _ptr(b), _ptr(cs), _ptr(b2), N, K,
+                                         _stream()), None, "op_fold_vectors")
+    return cs, b2
+
+
+def op_gemm_ln_producer(A, Bt, bias, resid, gamma, a_split=0, x16_split=0, ldb=0, w8_exp=0, ntp=6):
+    """-> (out32 [M,N], x16 (format x16_split), part [M, ntp, 2], nt)."""
+    dtype = A.dtype
+    M = A.shape[0]
+    K = A.shape[1] // (2 if a_split else 1)
+    N = Bt.shape[0]
+    out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    x16 = torch.zeros(M, N * (2 if x16_split else 1), device=A.device, dtype=dtype)
+    part = torch.zeros(M, ntp, 2, device=A.device, dtype=torch.float32)
+    nt = C.c_int(0)
+    _lib.check(lib.mvlpt_op_gemm_ln_producer(_TORCH2DT[dtype], _ptr(A.contiguous()), a_split, _ptr(Bt), ldb, w8_exp, M, N, K, _ptr(bias),
+                                             _ptr(resid), _ptr(gamma), x16_split, _ptr(out), _ptr(x16), _ptr(part), ntp, C.byref(nt),
+                                             _stream()), None, "op_gemm_ln_producer")
+    return out, x16, part, nt.value
+
+
+def op_gemm_folded(x16, Bt, colsum, bias2, part, nt, epi=_lib.EPI_STORE16, a_split=0, ldb=0, w8_exp=0, out2=False):
+    dtype = x16.dtype
+    M = x16.shape[0]
+    K = x16.shape[1] // (2 if a_split else 1)
+    N = Bt.shape[0]
+    wide = epi in (_lib.EPI_GELU_SPLIT, _lib.EPI_STORE_SPLIT)
+    out = torch.zeros(M, N * (2 if wide else 1), device=x16.device, dtype=dtype)
+    o2 = torch.empty(M, N, device=x16.device, dtype=dtype) if out2 else None
+    _lib.check(lib.mvlpt_op_gemm_folded(_TORCH2DT[dtype], epi, _ptr(x16), a_split, _ptr(Bt), ldb, w8_exp, M, N, K, _ptr(colsum), _ptr(bias2),
+                                        _ptr(part), part.shape[1], nt, _ptr(out), _ptr(o2), _stream()), None, "op_gemm_folded")
+    return (out, o2) if out2 else out

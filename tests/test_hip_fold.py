@@ -1,0 +1,164 @@
+"""LayerNorm folding (-m gpu; include/mvlpt_hip.h: mvlpt_set_ln_fold, mvlpt_op_gemm_ln_producer / gemm_folded): the GEMM in front of
+a LayerNorm hands round16(x * gamma) and per-row partial sums to the GEMM behind it, which applies mean / rstd in its epilogue.
+Replaces the stand-alone `ln_1` / `ln_2` calls of ResidualAttentionBlock.forward (clip/model.py:186-187) inside the towers.
+
+* kernel level: producer + consumer against fp32 torch (residual add, LayerNorm, linear [+ QuickGELU]) for every A-operand format
+  (single, hi|lo pair, mixed pair), every folded epilogue, all three tile geometries, ragged M; partial sums exact to fp32 round-off;
+* tower level: the five full-size reference fixtures with folding forced on (min_rows = 1) at the north_star 1e-3 bound;
+* determinism: bit-identical results run to run (no atomics: every tile owns its partial-sum slots)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import load_npz, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _E():
+    from mvlpt_amd import engine
+    return engine
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
+def _problem(M, N1, K1, N2, seed, dtype):
+    """x_new = A W1^T + b1 + resid ; y = LN(x_new) W2^T + b2   (N1 = width of the residual stream = K of the second GEMM)"""
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K1, generator=g)
+    W1 = (torch.randn(N1, K1, generator=g) * K1 ** -0.5).to(dtype).float()
+    b1 = torch.randn(N1, generator=g) * 0.1
+    resid = torch.randn(M, N1, generator=g) * 2.0 + 0.3 * torch.randn(M, 1, generator=g)      # rows with a mean of their own
+    resid[:, 7] += 25.0                                                                      # a massive-activation channel
+    gamma = 1.0 + 0.2 * torch.randn(N1, generator=g)
+    beta = 0.1 * torch.randn(N1, generator=g)
+    W2 = (torch.randn(N2, N1, generator=g) * N1 ** -0.5).to(dtype).float()
+    b2 = torch.randn(N2, generator=g) * 0.1
+    return A, W1, b1, resid, gamma, beta, W2, b2
+
+
+SHAPES = [(300, 768, 768, 2304), (1000, 512, 2048, 2048), (4096, 768, 768, 3072), (12608, 768, 3072, 2304), (50432, 768, 3072, 768 * 3)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N1,K1,N2", SHAPES)
+@pytest.mark.parametrize("epi_name", ["store16", "gelu"])
+def test_fold_single_operands(dtype, M, N1, K1, N2, epi_name):
+    E = _E()
+    L = E._lib
+    A, W1, b1, resid, gamma, beta, W2, b2 = _problem(M, N1, K1, N2, M + N2, dtype)
+    dev = "cuda"
+    A16 = A.to(dtype)
+    xref = A16.double() @ W1.double().t() + b1.double() + resid.double()
+    out32, x16, part, nt = E.op_gemm_ln_producer(A16.to(dev), W1.to(dtype).to(dev), b1.to(dev), resid.to(dev), gamma.to(dev))
+    assert relerr(out32, xref) < 2e-6 * K1 ** 0.5
+    # the partial sums are those of the fp32 output rows, tile by tile
+    bn = N1 // nt
+    got = part[:, :nt].double().cpu()
+    o = out32.double().cpu().view(M, nt, bn)
+    assert float((got[..., 0] - o.sum(-1)).abs().max()) <= 1e-4 * float(o.abs().sum(-1).max())
+    assert float((got[..., 1] - (o * o).sum(-1)).abs().max()) <= 1e-5 * float((o * o).sum(-1).max())
+    assert torch.equal(x16.cpu(), (out32.cpu() * gamma).to(dtype))                            # round16(x * gamma), bit-exact
+    cs, bias2 = E.op_fold_vectors(W2.to(dtype).to(dev), N1, gamma.to(dev), beta.to(dev), b2.to(dev))
+    assert relerr(cs, W2.double() @ gamma.double()) < 1e-5 and relerr(bias2, b2.double() + W2.double() @ beta.double()) < 1e-5
+    epi = {"store16": L.EPI_STORE16, "gelu": L.EPI_GELU}[epi_name]
+    res = E.op_gemm_folded(x16, W2.to(dtype).to(dev), cs, bias2, part, nt, epi=epi, out2=(epi == L.EPI_GELU))
+    y = torch.nn.functional.layer_norm(out32.double().cpu(), (N1,), gamma.double(), beta.double(), 1e-5) @ W2.double().t() + b2.double()
+    tol = 3e-3 if dtype == torch.float16 else 2.5e-2          # one 16-bit rounding of the operand and one of the output
+    if epi == L.EPI_GELU:
+        out, u = res
+        assert relerr(u, y) < tol
+        assert relerr(out, y * torch.sigmoid(1.702 * y)) < tol
+    else:
+        assert relerr(res, y) < tol
+    # ... and as close to the reference as the unfolded path (LayerNorm kernel + plain GEMM) is
+    h16 = E.op_layernorm_fwd(out32, gamma.to(dev), beta.to(dev), dtype)
+    plain = E.op_gemm(h16, W2.to(dtype).to(dev), L.EPI_STORE16, bias=b2.to(dev))
+    if epi == L.EPI_STORE16:
+        assert relerr(res, y) < 1.5 * relerr(plain, y) + 1e-4
+
+
+@pytest.mark.parametrize("fmt", ["pair", "mixed"])
+@pytest.mark.parametrize("M,N1,K1,N2", [(300, 768, 768, 2304), (7700, 512, 2048, 2048), (20000, 768, 768, 3072)])
+@pytest.mark.parametrize("epi_name", ["store_split", "gelu_split"])
+def test_fold_split_operands(fmt, M, N1, K1, N2, epi_name):
+    """Split towers: A and x16 are hi|lo pairs (a_split 1) or mixed pairs (a_split 2); the consumer's output is a pair again."""
+    E = _E()
+    L = E._lib
+    dtype, dev = torch.float16, "cuda"
+    A, W1, b1, resid, gamma, beta, W2, b2 = _problem(M, N1, K1, N2, M + 3, dtype)
+    xref = A.double() @ W1.double().t() + b1.double() + resid.double()
+    if fmt == "pair":
+        A2, W1p, W2p, ldb1, ldb2, e1, e2, sp = E.split_pair(A.to(dev), dtype), W1.to(dtype).to(dev), W2.to(dtype).to(dev), 0, 0, 0, 0, 1
+    else:
+        A2 = E.op_cast_mixed(A.to(dev), dtype)
+        W1p, e1 = E.op_pack_weight_mixed(W1.to(dev), dtype)
+        W2p, e2 = E.op_pack_weight_mixed(W2.to(dev), dtype)
+        ldb1, ldb2, sp = W1p.shape[1], W2p.shape[1], 2
+    out32, x16, part, nt = E.op_gemm_ln_producer(A2, W1p, b1.to(dev), resid.to(dev), gamma.to(dev), a_split=sp, x16_split=sp, ldb=ldb1, w8_exp=e1)
+    assert relerr(out32, xref) < (1e-5 if fmt == "pair" else 4e-5)
+    xg = out32.cpu() * gamma
+    val = (E.join_pair(x16) if fmt == "pair" else E.join_mixed(x16)).cpu()
+    # (fp16 lo halves bottom out at 2^-24 absolute: small elements are held to the bound of a 0.05-sized one)
+    assert float(((val - xg).abs() / xg.abs().clamp_min(0.05)).max()) < (2.0 ** -19 if fmt == "pair" else 2.0 ** -13)
+    W2_16 = W2p if fmt == "pair" else W2p[:, :N1].contiguous()
+    cs, bias2 = E.op_fold_vectors(W2_16, N1, gamma.to(dev), beta.to(dev), b2.to(dev))
+    epi = {"store_split": L.EPI_STORE_SPLIT, "gelu_split": L.EPI_GELU_SPLIT}[epi_name]
+    res = E.op_gemm_folded(x16, W2p, cs, bias2, part, nt, epi=epi, a_split=sp, ldb=ldb2, w8_exp=e2, out2=(epi == L.EPI_GELU_SPLIT))
+    y = torch.nn.functional.layer_norm(out32.double().cpu(), (N1,), gamma.double(), beta.double(), 1e-5) @ W2.double().t() + b2.double()
+    if epi == L.EPI_GELU_SPLIT:
+        out, u = res
+        want = y * torch.sigmoid(1.702 * y)
+        got = E.join_mixed(out) if fmt == "mixed" else E.join_pair(out)
+    else:
+        want, got = y, E.join_pair(res)                       # EPI_STORE_SPLIT always writes 16-bit pairs (the attention core's input)
+    assert relerr(got, want) < (2e-5 if fmt == "pair" else 1e-4), relerr(got, want)
+
+
+def test_fold_is_deterministic():
+    E = _E()
+    dtype, dev = torch.float16, "cuda"
+    A, W1, b1, resid, gamma, beta, W2, b2 = _problem(20000, 768, 768, 2304, 5, dtype)
+    args = (A.to(dtype).to(dev), W1.to(dtype).to(dev), b1.to(dev), resid.to(dev), gamma.to(dev))
+    cs, bias2 = E.op_fold_vectors(W2.to(dtype).to(dev), 768, gamma.to(dev), beta.to(dev), b2.to(dev))
+    ref = None
+    for _ in range(5):
+        out32, x16, part, nt = E.op_gemm_ln_producer(*args)
+        y = E.op_gemm_folded(x16, W2.to(dtype).to(dev), cs, bias2, part, nt)
+        cur = (out32.clone(), x16.clone(), part.clone(), y.clone())
+        if ref is not None:
+            assert all(torch.equal(a, b) for a, b in zip(ref, cur))
+        ref = cur
+
+
+FULL = [("ViT-B/32", "full_vitb32_coop_end"), ("ViT-B/16", "full_vitb16_coop_middle"), ("ViT-B/16", "full_vitb16_vpt_deep"),
+        ("ViT-B/16", "full_vitb16_upt_cut"), ("ViT-L/14@336px", "full_vitl14_336_upt_cut")]
+_clips = {}
+
+
+@pytest.mark.parametrize("arch_name,name", FULL)
+def test_full_size_fixtures_with_folding_forced_on(arch_name, name):
+    """At B = 4 the towers have 200 - 2 324 token rows and would keep the stand-alone LayerNorm (min_rows 4096): force the folded
+    path and hold it to the same bounds as tests/test_hip_model.py (training forward + backward, and the inference forward)."""
+    from mvlpt_amd.model import FrozenCLIP
+    from mvlpt_amd.weights import ARCHS, make_state_dict
+    from tests.golden_util import full_case_inputs
+    from tests.test_hip_model import GRAD_TOL_FP16, TOL_FP16, _check_inference, _inference_logits, build_model, run_case
+    if arch_name not in _clips:
+        _clips.clear()
+        sd = make_state_dict(ARCHS[arch_name], 2, include_token_embedding=True)
+        _clips[arch_name] = (FrozenCLIP(sd, compute_dtype="fp16"), sd)
+    clip, sd = _clips[arch_name]
+    clip.engine.set_ln_fold(2, 1)
+    try:
+        case = load_npz(name)
+        res = ARCHS[arch_name].image_resolution
+        image, pre, suf = full_case_inputs(case, sd, res)
+        model = build_model(case, clip, res, pre, suf)
+        run_case(case, model, image, TOL_FP16, GRAD_TOL_FP16)
+        _check_inference(case, _inference_logits(case, build_model(case, clip, res, pre, suf), image), name)
+    finally:
+        clip.engine.set_ln_fold(2, 4096)
