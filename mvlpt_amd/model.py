@@ -415,17 +415,18 @@ class _PromptedClipFn(torch.autograd.Function):
             cached_eval = False
         run_text = not ((coop_emb is None or cached_eval) and model._const_text_features is not None)
         suffix, layout = _text_inputs(model, pl)
-        pre = model._prefetched
-        model._prefetched = None
-        if pre is not None and vpt_emb is None and pre[:3] == (image.data_ptr(), tuple(image.shape), image._version):
-            def image_fwd(*_a, **_k):                 # features of this very tensor were computed ahead of time
-                torch.cuda.current_stream().wait_event(pre[4])
-                pre[3].record_stream(torch.cuda.current_stream())
-                return pre[3]
+        # features computed ahead of time (prefetch_image_features), keyed by the tensor they belong to
+        pre = model._prefetched.pop((image.data_ptr(), tuple(image.shape), image._version), None) if vpt_emb is None else None
+        if pre is not None:
+            def image_fwd(*_a, **_k):
+                torch.cuda.current_stream().wait_event(pre[1])
+                pre[0].record_stream(torch.cuda.current_stream())
+                return pre[0]
         else:
-            if pre is not None:
-                # a prefetch for ANOTHER tensor is (or was) writing the image-tower workspace on its own stream
-                torch.cuda.current_stream().wait_event(pre[4])
+            # prefetches for OTHER tensors are (or were) writing the image-tower workspace on their own stream: this forward
+            # runs the tower itself, behind them (and they stay available to the forwards they were made for)
+            for other in model._prefetched.values():
+                torch.cuda.current_stream().wait_event(other[1])
             image_fwd = eng.image_fwd
         shard = model._class_shard if (run_text and coop_emb is not None) else None
         side = model._side_stream if (run_text and model.overlap_towers and shard is None) else None
@@ -561,7 +562,7 @@ class CustomCLIP(nn.Module):
         self._eval_text_cache = None
         self.trim_text_to_eot = False
         self._prefetch_stream = None
-        self._prefetched = None
+        self._prefetched = {}                     # (data_ptr, shape, version) of an image tensor -> (features, event)
         self._fwd_generation = 0
         self._side_stream = torch.cuda.Stream(device=clip_model.device) if torch.cuda.is_available() else None
         self._text_partition = None
@@ -615,30 +616,42 @@ class CustomCLIP(nn.Module):
 
     def prefetch_image_features(self, image) -> bool:
         """Software pipelining across steps: with no visual prompts the image tower is a pure function of the image
-        (frozen weights, trainers/mvlpt.py:855-858), so the features of the NEXT batch can be computed on a third
-        HIP stream while the current step's text-tower backward (small launches that cannot fill the chip) and
-        optimizer run.  `forward(image)` picks the result up when it is called with the same tensor."""
+        (frozen weights, trainers/mvlpt.py:855-858), so the features of the NEXT batch are computed on a third HIP stream
+        beside the current step's text tower (forward, backward: small launches that cannot fill the chip), head and
+        optimizer.  `forward(image)` picks the result up when it is called with the same tensor.  Successive prefetches
+        queue up on that one stream (they share the tower workspace), so the trainer can issue the one for batch i+1 BEFORE
+        step i's own forward: the image stream then never waits for a step's logits."""
         pl = self.prompt_learner
         if pl.vpt_embeddings is not None or self._side_stream is None:
             return False
+        key = (image.data_ptr(), tuple(image.shape), image._version)
+        if key in self._prefetched:
+            return True
         main = torch.cuda.current_stream()
         if self._prefetch_stream is None:
             self._prefetch_stream = torch.cuda.Stream(device=self.clip_model.device)
         st = self._prefetch_stream
-        st.wait_stream(main)                       # the tower workspace of the previous image forward is free
+        # the image tensor was produced (uploaded) on the main stream; an image forward that ran on the main stream itself
+        # (no prefetch: the first step, an evaluation) must be done with the tower workspace
+        ready = torch.cuda.Event()
+        ready.record(main)
+        st.wait_event(ready)
         with torch.cuda.stream(st):
             feat = self.engine.image_fwd(image, None, None, save_for_bwd=False)
             ev = torch.cuda.Event()
             ev.record(st)
-        self._prefetched = (image.data_ptr(), tuple(image.shape), image._version, feat, ev)
+        image.record_stream(st)
+        if len(self._prefetched) >= 4:            # never picked up (a loop that reads ahead without consuming): keep the newest
+            self._prefetched.pop(next(iter(self._prefetched)))
+        self._prefetched[key] = (feat, ev)
         return True
 
     def drop_prefetch(self) -> None:
-        """Forget a prefetched image forward that nobody will pick up (the loop left the loader early): the main stream
+        """Forget prefetched image forwards that nobody will pick up (the loop left the loader early): the main stream
         waits for the side stream so that the image-tower workspace is quiescent for whatever runs next."""
-        pre, self._prefetched = self._prefetched, None
-        if pre is not None:
-            torch.cuda.current_stream().wait_event(pre[4])
+        pre, self._prefetched = self._prefetched, {}
+        for feat, ev in pre.values():
+            torch.cuda.current_stream().wait_event(ev)
 
     def forward(self, image, task=None):
         coop_emb, vpt_emb, vpt_emb_deep = self.prompt_learner.forward_mvlpt_proj(self.dtype)

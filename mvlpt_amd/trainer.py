@@ -111,6 +111,12 @@ def build_lr_scheduler(optim, optim_cfg):
     return _ConstantWarmupCosine(optim, optim_cfg)
 
 
+# Enqueue order of MVLPT.forward_backward: the next batch's image tower BEFORE (1) or behind (0, default) this step's own forward.
+# Measured (NOTES_experiments.md, round 4): enqueued early the image stream never waits for a step's logits, but the step gets no
+# shorter — 14.18-14.21 vs 14.11-14.12 ms in the same run: what bounds the step is the work of the two towers, not that bubble.
+_PREFETCH_EARLY = os.environ.get("MVLPT_PREFETCH_EARLY", "0") != "0"
+
+
 class TrainerX:
     """The slice of dassl.engine.TrainerX the reference relies on."""
 
@@ -448,10 +454,17 @@ class MVLPT(TrainerX):
         if len(label.shape) > 1 and label.shape[-1] > 1:                # :914-916
             label = label.float()
             label = label / label.sum(dim=-1, keepdim=True)
+        early = next_batch is not None and _PREFETCH_EARLY
+        if early:
+            # batch i+1: its H2D copy and its image tower are enqueued BEFORE step i's own forward, so the image stream
+            # goes from one batch straight into the next while this step's text tower, head and optimizer run beside it
+            parsed = self.parse_batch_train(next_batch)
+            self._parsed_ahead = (next_batch, parsed)
+            self.model.prefetch_image_features(parsed[0])
         output = self.model(image, task=tasks_)
         loss = self.model.cross_entropy(output, label)                  # F.cross_entropy (:931) as a HIP kernel
-        if next_batch is not None:
-            parsed = self.parse_batch_train(next_batch)        # the H2D copy of batch i+1 overlaps step i as well
+        if next_batch is not None and not early:                        # the H2D copy of batch i+1 and its image tower overlap this step's backward
+            parsed = self.parse_batch_train(next_batch)
             self._parsed_ahead = (next_batch, parsed)
             self.model.prefetch_image_features(parsed[0])
         self.model_backward_and_update(loss)

@@ -168,10 +168,10 @@ def test_lookahead_reaches_a_plain_dassl_loop(tmp_path):
     # leaving the loop early drops the pending prefetch instead of leaving it for an unrelated forward
     it = iter(tr.train_loader_x)
     tr.forward_backward(next(it))
-    assert tr.model._prefetched is not None
+    assert len(tr.model._prefetched) == 1
     it.close()
     tr.end_of_epoch_loop()
-    assert tr.model._prefetched is None and tr._parsed_ahead is None and tr.next_batch is None
+    assert not tr.model._prefetched and tr._parsed_ahead is None and tr.next_batch is None
 
 
 def test_three_reference_train_steps_on_the_hip_engine(tmp_path):
