@@ -166,8 +166,8 @@ int mvlpt_op_cast_mixed(int dtype, const float* in, void* out, int64_t rows, int
 /* ---- LayerNorm folding at kernel level (see mvlpt_set_ln_fold): LN(x) W^T + b = rstd_r (x gamma) W^T - rstd_r mean_r (W gamma) + (b + W beta).
  * fold_vectors: colsum = W gamma, bias2 = b + W beta from the PACKED 16-bit weight W16 [N, ld] (load time).
  * gemm_ln_producer: out32 = A Bt^T + bias + resid (as epilogue 2) AND x16 = round16(out32 * gamma) in the A-operand format
- *   x16_split (0 [M,N], 1 hi|lo pair [M,2N], 2 mixed pair) AND part[(row * ntp + tile) * 2 ..] = {sum, sum of squares} of the row over
- *   each of the *nt N-tiles of the launch (ntp: slots per row, even, >= *nt, <= 6).  A: a_split 0 / 1 / 2 as in op_gemm*.
+ *   x16_split (0 [M,N], 1 hi|lo pair [M,2N], 2 mixed pair) AND part[(row * ntp + j) * 2 ..] = {sum, sum of squares} of the row over
+ *   output columns 128 j .. 128 j + 127, *nt = N / 128 slots whatever tile geometry the launch uses (ntp: slots per row, even, >= *nt, <= 8).  A: a_split 0 / 1 / 2 as in op_gemm*.
  * gemm_folded: epilogue `epi` (0, 1, 5, 7) on A16 = x16 with the normalisation applied from `part` (K = length of the rows). */
 int mvlpt_op_fold_vectors(int dtype, const void* W16, int ld, const float* gamma, const float* beta, const float* b, float* colsum,
                           float* bias2, int N, int K, mvlpt_stream_t stream);

@@ -964,6 +964,185 @@ __global__ __launch_bounds__(RNW * 64) void attn32r_bwd_kernel(Attn32BwdArgs a) 
     }
   }
 }
+// ------------------------------------------------------------------------------------------------ resident + persistent
+// The resident forward above leaves its staging exposed: one workgroup per CU (104 KiB), so nothing overlaps a head's 104 KiB
+// of LDS-DMA with another head's arithmetic (ablation: staging alone 112 of 264 us).  Here a workgroup WALKS the (sequence, head)
+// list and the next head's operands land while the current one is multiplied: THREE pair buffers (hi + lo image, 52 KiB each,
+// 156 KiB) in rotation — head i has K in buffer 2i mod 3 and V in 2i+1 mod 3; K of head i+1 is requested at the top of head i
+// into the buffer V of head i-1 has just left, V of head i+1 behind the S phase of head i into K_i's buffer.  For that the two
+// own tiles of a wave go through the S phase together (every K fragment feeds both: half the fragment reads), then — one barrier,
+// K_i is dead — through softmax and P.V together.  Every wave issues the same number of DMA instructions per matrix (8: slabs
+// past the 26th re-copy the last one) so the counted waits are compile-time constants: at the top of a head everything but the
+// wave's own output stores of the previous head (vmcnt retires in order) has landed.
+namespace {
+constexpr int RBUF = 2 * RIMG;                 // one pair buffer: hi image, lo image
+constexpr int RLDS_P = 3 * RBUF;
+template <typename T>
+__device__ __forceinline__ void stage_res8(char* buf, const T* src, size_t lo_off, size_t ld, int L, int wave, int lane) {
+  const int srow = lane >> 3, chunk = (lane & 7) ^ srow;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int sl = wave + RNW * i;
+    sl = sl < RROWS / 8 ? sl : RROWS / 8 - 1;
+    int row = sl * 8 + srow;
+    row = row < L ? row : L - 1;
+    const T* g = src + (size_t)row * ld + chunk * 8;
+    dma_raw<16>(g, buf + sl * 1024);
+    dma_raw<16>(g + lo_off, buf + RIMG + sl * 1024);
+  }
+}
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(RNW * 64) void attn32p_fwd_kernel(Attn32Args a, int total) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  using v8 = typename Vec<T>::v8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+  const int L = a.L, d = a.H * 64, G = gridDim.x;
+  const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d;
+  const int nt = (L + 15) >> 4;
+  const bool two = wave + RNW < nt;          // the wave's second tile exists
+  auto head_base = [&](int item) -> const T* {
+    const int n = item / a.H, h = item - n * a.H;
+    return (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
+  };
+  auto load_q = [&](const T* base, v8 (&Qh)[2][2], v8 (&Ql)[2][2]) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int q = (wave + o * RNW) * 16 + fr;
+      load_own_pair<T>(Qh[o], Ql[o], base + (size_t)(q < L ? q : L - 1) * ld, lo, fg);
+    }
+  };
+  int item = blockIdx.x;
+  if (item >= total) return;
+  int kbuf = 0;
+  v8 Qh[2][2], Ql[2][2];
+  {
+    const T* base = head_base(item);
+    stage_res8<T>(sm, base + d, lo, ld, L, wave, lane);                  // K_0
+    stage_res8<T>(sm + RBUF, base + 2 * d, lo, ld, L, wave, lane);       // V_0
+    load_q(base, Qh, Ql);
+  }
+  for (bool first = true; item < total; item += G, first = false) {
+    const int n = item / a.H, h = item - n * a.H;
+    char* const Kb = sm + kbuf * RBUF;
+    char* const Vb = sm + (kbuf + 1 >= 3 ? kbuf - 2 : kbuf + 1) * RBUF;
+    char* const Nb = sm + (kbuf + 2 >= 3 ? kbuf - 1 : kbuf + 2) * RBUF;
+    const int next = item + G;
+    // everything this wave requested has landed, except (vmcnt retires in order) its output stores of the previous head
+    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (two) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // everybody's pieces of K_i, V_i are in; everybody is done with V_(i-1)
+    if (next < total) stage_res8<T>(Nb, head_base(next) + d, lo, ld, L, wave, lane);          // K_(i+1)
+    // ---- S phase: both own tiles against every key tile
+    f32x4 S[2][RNT];
+#pragma unroll
+    for (int kt = 0; kt < RNT; ++kt) {
+      S[0][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; S[1][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < nt) {
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const v8 ah = frag_rows<T>(Kb, kt, ks, fr, fg), al = frag_rows<T>(Kb + RIMG, kt, ks, fr, fg);
+#pragma unroll
+          for (int o = 0; o < 2; ++o) {
+            if (o == 1 && !two) continue;
+            acc[o][ks] = mfma16<T>(ah, Qh[o][ks], f32x4{0.f, 0.f, 0.f, 0.f});
+            acc[o][ks] = mfma16<T>(ah, Ql[o][ks], acc[o][ks]);
+            acc[o][ks] = mfma16<T>(al, Qh[o][ks], acc[o][ks]);
+          }
+        }
+        S[0][kt] = acc[0][0] + acc[0][1];
+        if (two) S[1][kt] = acc[1][0] + acc[1][1];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // K_i is dead
+    if (next < total) {
+      const T* nb = head_base(next);
+      stage_res8<T>(Kb, nb + 2 * d, lo, ld, L, wave, lane);                                   // V_(i+1)
+      load_q(nb, Qh, Ql);                                                                     // Q_(i+1): Q_i is dead too
+    }
+    const int qlim = a.q_rows > 0 ? (a.q_rows < L ? a.q_rows : L) : L;
+    // ---- softmax of both tiles
+    float mx[2], sum[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      mx[o] = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < RNT; ++kt)
+        if (kt < nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kk = 16 * kt + 4 * fg + r;
+            S[o][kt][r] = kk < L ? S[o][kt][r] : -INFINITY;
+            mx[o] = fmaxf(mx[o], S[o][kt][r]);
+          }
+        }
+      mx[o] = quad_max(mx[o]);
+      const float msc = mx[o] * SC2;
+      sum[o] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < RNT; ++kt)
+        if (kt < nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { S[o][kt][r] = __builtin_amdgcn_exp2f(fmaf(S[o][kt][r], SC2, -msc)); sum[o] += S[o][kt][r]; }
+        }
+      sum[o] = quad_sum(sum[o]);
+    }
+    // ---- O = P V: every V^T fragment feeds both tiles
+    f32x4 O[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) O[o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < (RNT + 1) / 2; ++kb) {
+      if (2 * kb >= nt) continue;
+      const bool half = 2 * kb + 1 >= nt;                 // the block's second tile does not exist (wave-uniform)
+      v8 ph[2], pl[2];
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          T x, y;
+          split16<T>(S[o][2 * kb][e], x, y); ph[o][e] = x; pl[o][e] = y;
+          split16<T>(2 * kb + 1 < RNT ? S[o][2 * kb + 1 < RNT ? 2 * kb + 1 : 0][e] : 0.f, x, y); ph[o][e + 4] = x; pl[o][e + 4] = y;
+        }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const v8 vh = half ? frag_vt_half<T>(Vb, kb, dt, fr, fg) : frag_vt<T>(Vb, kb, dt, fr, fg);
+        const v8 vl = half ? frag_vt_half<T>(Vb + RIMG, kb, dt, fr, fg) : frag_vt<T>(Vb + RIMG, kb, dt, fr, fg);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          if (o == 1 && !two) continue;
+          O[o][dt] = mfma16<T>(vh, ph[o], O[o][dt]);
+          O[o][dt] = mfma16<T>(vh, pl[o], O[o][dt]);
+          O[o][dt] = mfma16<T>(vl, ph[o], O[o][dt]);
+        }
+      }
+    }
+    // ---- outputs (8 stores per existing tile + lse)
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      if (o == 1 && !two) continue;
+      const int q = (wave + o * RNW) * 16 + fr;
+      const bool ok = q < qlim;
+      const int qc = ok ? q : 0;
+      const float inv = 1.f / sum[o];
+      T* orow = (T*)a.out_split + ((size_t)n * L + qc) * (2 * (size_t)d) + h * 64;
+      if (ok) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store_pair4_m<T>(orow + 16 * dt + 4 * fg, d, h * 64 + 16 * dt + 4 * fg, O[o][dt] * inv, a.out_lo8);
+        if (a.lse && fg == 0) a.lse[((size_t)n * a.H + h) * L + q] = mx[o] * SCALE + logf(sum[o]);
+      }
+    }
+    kbuf = kbuf + 2 >= 3 ? kbuf - 1 : kbuf + 2;
+  }
+}
+
 static bool attn32_resident(int L, int causal) {
   static const bool on = !(getenv("MVLPT_ATTN32_RESIDENT") && atoi(getenv("MVLPT_ATTN32_RESIDENT")) == 0);
   return on && !causal && L <= RROWS;
@@ -1020,6 +1199,15 @@ static hipError_t fwd_t(const Attn32Args& a, hipStream_t s) {
     return hipGetLastError();
   }
   if (attn32_resident(a.L, a.causal)) {
+    // persistent variant (next head's K / V land under this head's arithmetic): full-sequence launches with more heads than CUs
+    static const bool persist = !(getenv("MVLPT_ATTN32_PERSIST") && atoi(getenv("MVLPT_ATTN32_PERSIST")) == 0);
+    const int total = a.N * a.H, cus = stream_cus(s);
+    if (persist && a.q_rows <= 0 && total >= 2 * cus) {
+      static bool setp = false;
+      if (!setp) { set_lds(attn32p_fwd_kernel<T>, RLDS_P); setp = true; }
+      hipLaunchKernelGGL((attn32p_fwd_kernel<T>), dim3(cus), dim3(RNW * 64), RLDS_P, s, a, total);
+      return hipGetLastError();
+    }
     static bool set = false;
     if (!set) { set_lds(attn32r_fwd_kernel<T>, RLDS); set = true; }
     hipLaunchKernelGGL((attn32r_fwd_kernel<T>), dim3(a.H, a.N), dim3(RNW * 64), RLDS, s, a);

@@ -117,6 +117,7 @@ struct TowerW { int width = 0, layers = 0, heads = 0; std::vector<Block> blocks;
 struct TowerState {
   bool valid = false, saved = false, causal = false;
   bool exact = false;                    // split-precision operands + pair-product attention (see DESIGN.md "Precision modes")
+  int wide_pitch = 0;                    // split towers: row pitch of a16 / du16 (0: dense)
   int xs = 0;                            // GEMM A operands: 0 single 16-bit, 1 16-bit pair, 2 mixed pair (hi + e5m2 residual byte)
   int N = 0, L = 0, d = 0, H = 0, layers = 0;
   std::vector<float*> x;                 // 2*layers+1 entries (all equal when !saved)
@@ -132,7 +133,7 @@ struct TowerState {
   float* part[2] = {nullptr, nullptr};   // [T][FOLD_NTP][2]
   int nt[2] = {0, 0}, ntp[2] = {0, 0};   // slots in use / slots per row, as the last producer wrote them
 };
-constexpr int FOLD_NTP = 6;              // slots per row the buffers are sized for (gemm.hip: FOLD_MAX_NTP)
+constexpr int FOLD_NTP = 8;              // slots per row the buffers are sized for (gemm.hip: FOLD_MAX_NTP)
 
 enum ProfClass { PC_GEMM = 0, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD, PC_GLUE, PC_HEAD, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm_bt", "attention_fwd", "attention_bwd", "layernorm_fwd", "layernorm_bwd",
@@ -207,9 +208,10 @@ struct Fold {
   const float* fold_part = nullptr; const float* fold_colsum = nullptr; int fold_ntp = 0, fold_nt = 0;                   // consumer
 };
 hipError_t gemm(Engine* E, int epi, const void* A, WRef Bt, int M, int N, int K, const float* bias, const void* aux,
-                const float* resid, void* out, void* out2, hipStream_t s, int dtype = -1, int a_split = 0, const Fold* f = nullptr) {
+                const float* resid, void* out, void* out2, hipStream_t s, int dtype = -1, int a_split = 0, const Fold* f = nullptr,
+                int lda = 0, int ldo = 0) {
   GemmArgs g{A, Bt.p, M, N, K, bias, aux, resid, out, out2};
-  g.a_split = a_split; g.ldb = Bt.ld; g.w8_exp = Bt.e8;
+  g.a_split = a_split; g.ldb = Bt.ld; g.w8_exp = Bt.e8; g.lda = lda; g.ldo = ldo;
   if (f) {
     g.ln_gamma = f->ln_gamma; g.ln_x16 = f->ln_x16; g.ln_split = f->ln_split; g.ln_part = f->ln_part; g.ln_ntp = f->ln_ntp;
     g.fold_part = f->fold_part; g.fold_colsum = f->fold_colsum; g.fold_ntp = f->fold_ntp; g.fold_nt = f->fold_nt;
@@ -261,13 +263,19 @@ size_t tower_bytes(const TowerW& W, int N, int L, bool save, bool exact) {
   b += (save ? nl : 1) * align256(T * d * 2 * X);                    // attn
   b += (save ? nl : 1) * align256((size_t)N * H * L * 4);            // lse
   b += (save ? nl : 1) * align256(T * 4 * d * 2);                    // u
-  b += align256(T * 4 * d * 2 * X);                                  // a16
+  b += align256(T * (4 * d * 2 * X + 128));                          // a16 (pair rows padded: wide_pitch)
   b += 2 * align256(T * FOLD_NTP * 8);                               // LayerNorm-folding partials
   if (save) {
-    b += 2 * align256(T * d * 4) + 2 * align256(T * d * 2 * X) + (align256(T * 4 * d * 2) + align256(T * 3 * d * 2)) * X;
+    b += 2 * align256(T * d * 4) + 2 * align256(T * d * 2 * X) + (align256(T * 4 * d * 2) + align256(T * 3 * d * 2)) * X + align256(T * 128);
     b += align256((size_t)N * H * L * 4) + 256;
   }
   return b + 4096;
+}
+// row pitch (16-bit elements) of the pair tensors between the two MLP GEMMs ([T, 2 * 4d]: a16, du16; GemmArgs::lda / ldo): rows
+// whose dense pitch is a multiple of 4 KiB get 128 bytes more (every CLIP width: 16 d bytes)
+int wide_pitch(int cols) {
+  static const int on = getenv("MVLPT_WIDE_PITCH") ? atoi(getenv("MVLPT_WIDE_PITCH")) : 1;
+  return on && (4 * cols) % 4096 == 0 ? 2 * cols + 64 : 0;
 }
 void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool save, bool causal, bool exact, int xs) {
   const size_t T = (size_t)N * L, d = W.width, H = W.heads, X = exact ? 2 : 1; const int nl = W.layers;
@@ -285,12 +293,13 @@ void carve_tower(Bump& bp, const TowerW& W, TowerState& st, int N, int L, bool s
     st.lse[l] = fresh ? bp.take<float>((size_t)N * H * L) : st.lse[0];
     st.u[l] = fresh ? bp.take_bytes(T * 4 * d * 2) : st.u[0];
   }
-  st.a16 = bp.take_bytes(T * 4 * d * 2 * X);
+  st.a16 = bp.take_bytes(T * (4 * d * 2 * X + 128));
+  st.wide_pitch = exact ? wide_pitch(4 * (int)d) : 0;
   st.part[0] = bp.take<float>(T * FOLD_NTP * 2); st.part[1] = bp.take<float>(T * FOLD_NTP * 2);
   if (save) {
     st.dx32 = bp.take<float>(T * d);
     st.dx16 = bp.take_bytes(T * d * 2 * X); st.dh32 = bp.take<float>(T * d); st.dO16 = bp.take_bytes(T * d * 2 * X);
-    st.du16 = bp.take_bytes(T * 4 * d * 2 * X); st.dqkv16 = bp.take_bytes(T * 3 * d * 2 * X);
+    st.du16 = bp.take_bytes(T * (4 * d * 2 * X + 128)); st.dqkv16 = bp.take_bytes(T * 3 * d * 2 * X);
     st.delta = bp.take<float>((size_t)N * H * L);
     st.scale_dev = bp.take<float>(4);   // {scale, 1/scale, amax scratch, pad}
   }
@@ -327,7 +336,7 @@ bool fold_producer(Engine* E, TowerState& st, int which, int M, int N, int K, co
   q.M = M; q.N = N; q.K = K; q.a_split = st.xs;
   const int bn = gemm_tile_n(E->dt, EPI_RESID32_LN, q, s);      // the launcher's N-tile for this problem on this stream
   if (bn <= 0 || N % bn) return false;
-  const int nt = N / bn, ntp = (nt + 1) & ~1;
+  const int nt = N / 128, ntp = (nt + 1) & ~1;          // one slot per 128 output columns, whatever the tile geometry
   if (ntp > FOLD_NTP) return false;
   *f = Fold();
   f->ln_gamma = ln.g; f->ln_x16 = st.h16; f->ln_split = st.xs; f->ln_part = st.part[which]; f->ln_ntp = ntp;
@@ -359,17 +368,18 @@ int block_fwd_x(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s
   if (p2) ff = fold_consumer(st, 1, B.fc);
   else HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, B.ln2, st.h16, T, d, s, st.xs));
   HIPCHK(E, gemm(E, EPI_GELU_SPLIT, st.h16, B.fc.fw(), T, 4 * d, d, p2 ? B.fc.fold_b : B.fc.b, nullptr, nullptr, st.a16, st.saved ? st.u[l] : nullptr, s, -1, st.xs,
-                 p2 ? &ff : nullptr));
+                 p2 ? &ff : nullptr, 0, st.wide_pitch));
   const bool p1 = next_ln1 && fold_producer(E, st, 0, T, d, 4 * d, *next_ln1, s, &fp);
-  HIPCHK(E, gemm(E, p1 ? EPI_RESID32_LN : EPI_RESID32, st.a16, B.pr.fw(), T, d, 4 * d, B.pr.b, nullptr, xmid, xout, nullptr, s, -1, st.xs, p1 ? &fp : nullptr));
+  HIPCHK(E, gemm(E, p1 ? EPI_RESID32_LN : EPI_RESID32, st.a16, B.pr.fw(), T, d, 4 * d, B.pr.b, nullptr, xmid, xout, nullptr, s, -1, st.xs, p1 ? &fp : nullptr,
+                 st.wide_pitch, 0));
   if (produced) *produced = p1;
   return 0;
 }
 int block_bwd_x(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
   const Block& B = W.blocks[l];
   const int T = st.N * st.L, d = st.d;
-  HIPCHK(E, gemm(E, EPI_GELUBWD_SPLIT, st.dx16, B.pr.bw(), T, 4 * d, d, nullptr, st.u[l], nullptr, st.du16, nullptr, s, -1, st.xs));
-  HIPCHK(E, gemm(E, EPI_STORE32, st.du16, B.fc.bw(), T, d, 4 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, st.xs));
+  HIPCHK(E, gemm(E, EPI_GELUBWD_SPLIT, st.dx16, B.pr.bw(), T, 4 * d, d, nullptr, st.u[l], nullptr, st.du16, nullptr, s, -1, st.xs, nullptr, 0, st.wide_pitch));
+  HIPCHK(E, gemm(E, EPI_STORE32, st.du16, B.fc.bw(), T, d, 4 * d, nullptr, nullptr, nullptr, st.dh32, nullptr, s, -1, st.xs, nullptr, st.wide_pitch, 0));
   HIPCHK(E, ln_bwd(E, st.dh32, DT_F32, st.x[2 * l + 1], nullptr, 1, B.ln2, st.dx32, st.dx32, st.dx16, T, d, s, -1, st.xs));
   HIPCHK(E, gemm(E, EPI_STORE_SPLIT, st.dx16, B.o.bw(), T, d, d, nullptr, nullptr, nullptr, st.dO16, nullptr, s, -1, st.xs));
   if (int rc = attn32_bwd(E, st, l, s)) return rc;
@@ -1173,8 +1183,8 @@ int mvlpt_op_gemm_ln_producer(int dtype, const void* A, int a_split, const void*
   g.a_split = a_split; g.ldb = ldb; g.w8_exp = w8_exp;
   g.ln_gamma = gamma; g.ln_x16 = x16; g.ln_split = x16_split; g.ln_part = part; g.ln_ntp = ntp;
   const int bn = gemm_tile_n(dtype, EPI_RESID32_LN, g, (hipStream_t)stream);
-  if (bn <= 0 || N % bn || N / bn > ntp) { g_create_err = "gemm_ln_producer: ntp smaller than the number of N-tiles of this launch"; return MVLPT_ERR_ARG; }
-  if (nt) *nt = N / bn;
+  if (bn <= 0 || N % bn || N / 128 > ntp) { g_create_err = "gemm_ln_producer: ntp smaller than N / 128"; return MVLPT_ERR_ARG; }
+  if (nt) *nt = N / 128;
   OPCHK(launch_gemm(dtype, EPI_RESID32_LN, g, (hipStream_t)stream));
   return 0;
 }

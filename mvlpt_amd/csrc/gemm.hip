@@ -72,24 +72,28 @@ struct SlabRows {
 
 // LayerNorm folding (kernels.h): the 16 KiB LDS region behind the ring.  Consumer: the partial sums of the tile's rows,
 // [row][ntp] float2, copied there by LDS-DMA with the tile's last K-stage.  Producer: [row][wave column] float2 of this tile.
-constexpr int XLDS_BYTES = 16384;
-constexpr int XLDS_COLSUM = 12288, XLDS_BIAS = 13312;   // consumer: the tile's colsum / bias slices (<= 256 floats each) behind <= 12 KiB of partials
-constexpr int XLDS_COEF = 14336;                         // consumer: {rstd, -rstd * mean} of the tile's rows (256 x 8 B), written once per tile
-constexpr int FOLD_MAX_NTP = 6;                          // 256 rows x 6 slots x 8 B = 12 KiB
+constexpr int XLDS_BYTES = 16384, XLDS_BYTES_WIDE = 20480;   // rows of up to 6 / 8 slots (d <= 768 / <= 1024)
+// consumer tables behind the partials (at xlds + xlds_tab(ntp)): the tile's colsum / bias slices (<= 256 floats each) and
+// {rstd, -rstd * mean} of the tile's rows (256 x 8 B), written once per tile
+constexpr int XLDS_COLSUM = 0, XLDS_BIAS = 1024, XLDS_COEF = 2048;
+constexpr int FOLD_MAX_NTP = 8;                          // one slot per 128 columns: rows up to 1024 wide
+__host__ __device__ constexpr int xlds_tab(int ntp) { return ntp > 6 ? 16384 : 12288; }      // 256 rows x ntp slots x 8 B
+__host__ __device__ constexpr int xlds_bytes(int ntp) { return ntp > 6 ? XLDS_BYTES_WIDE : XLDS_BYTES; }
 constexpr float FOLD_LN_EPS = 1e-5f;      // = LN_EPS of norm.hip (clip/model.py:153-159)
 struct FoldCtx {
   char* xl;      // the region
+  char* tab;     // consumer: its tables (colsum, bias, row coefficients)
   int mrel;      // first row of this wave's 64x64 block inside the tile
   int wn, wcn;   // column block of the wave / number of column blocks (producer)
   int xs;        // producer: format of the 16-bit copy (GemmArgs::ln_split; a compile-time 2 in the mixed-pair kernels)
 };
 // {rstd, -rstd * mean} of tile row `row_rel`: the table fold_build_coef left behind the partials
-__device__ __forceinline__ void fold_row_coef(const GemmArgs&, const char* xl, int row_rel, float& a, float& cc) {
-  const float2 q = *(const float2*)(xl + XLDS_COEF + row_rel * 8);
+__device__ __forceinline__ void fold_row_coef(const GemmArgs&, const char* tab, int row_rel, float& a, float& cc) {
+  const float2 q = *(const float2*)(tab + XLDS_COEF + row_rel * 8);
   a = q.x; cc = q.y;
 }
 // ... built once per tile (thread r = tile row r) from the row's partial sums, summed in slot order: deterministic
-__device__ __forceinline__ void fold_build_coef(const GemmArgs& g, char* xl, int row_rel) {
+__device__ __forceinline__ void fold_build_coef(const GemmArgs& g, char* xl, char* tab, int row_rel) {
   float a, cc;
   const f32x4* p = (const f32x4*)(xl + (size_t)row_rel * g.fold_ntp * 8);
   float s1 = 0.f, s2 = 0.f;
@@ -103,7 +107,7 @@ __device__ __forceinline__ void fold_build_coef(const GemmArgs& g, char* xl, int
   const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
   a = rsqrtf(var + FOLD_LN_EPS);
   cc = -a * mean;
-  *(float2*)(xl + XLDS_COEF + row_rel * 8) = float2{a, cc};
+  *(float2*)(tab + XLDS_COEF + row_rel * 8) = float2{a, cc};
 }
 // sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: quad butterflies, then the two mirrors.
 // VALU only (ds_bpermute-based shuffles would put ~8 LDS round trips into every row segment of the epilogue)
@@ -139,7 +143,8 @@ __device__ __forceinline__ void store_a16(void* base, int split, size_t m, int N
   }
 }
 
-template <typename T, int EPI_, typename Rows16, typename Rows32>
+// H0, H1: the 32-row halves of the wave's 64x64 block this call stores (the K-split kernel gives each of its two wave groups one)
+template <typename T, int EPI_, typename Rows16, typename Rows32, int H0 = 0, int H1 = 2>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&acc)[4][4], int mbase, int nbase, int lane,
                                                Rows16 rows16, Rows32 rows32, FoldCtx fc) {
   using v4 = typename Vec<T>::v4;
@@ -163,19 +168,19 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
       T* outp = (T*)(which == 0 ? g.out : g.out2);
       if (which == 1 && !outp) break;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int half = H0; half < H1; ++half) {
         if constexpr (fold) {
           // the tile's colsum / bias slices sit in LDS (ds_read: no vmcnt, nothing to keep in registers across the stores).
           // All LDS reads of the half first (two rows' partials, four column-vector pairs), then the arithmetic: read-then-use
           // per (row, column block) would expose one LDS round trip 32 times per tile
           float fa[2], fcc[2];
 #pragma unroll
-          for (int ii = 0; ii < 2; ++ii) fold_row_coef(g, fc.xl, fc.mrel + (half * 2 + ii) * 16 + fr, fa[ii], fcc[ii]);
+          for (int ii = 0; ii < 2; ++ii) fold_row_coef(g, fc.tab, fc.mrel + (half * 2 + ii) * 16 + fr, fa[ii], fcc[ii]);
           f32x4 sj[4], bj[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            sj[j] = *(const f32x4*)(fc.xl + XLDS_COLSUM + (fc.wn * 64 + j * 16 + fg * 4) * 4);
-            bj[j] = *(const f32x4*)(fc.xl + XLDS_BIAS + (fc.wn * 64 + j * 16 + fg * 4) * 4);
+            sj[j] = *(const f32x4*)(fc.tab + XLDS_COLSUM + (fc.wn * 64 + j * 16 + fg * 4) * 4);
+            bj[j] = *(const f32x4*)(fc.tab + XLDS_BIAS + (fc.wn * 64 + j * 16 + fg * 4) * 4);
           }
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii)
@@ -225,7 +230,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
     v4 uv[4][4];
     if constexpr (RESID || EPI == EPI_GELUBWD || EPI == EPI_GELUBWD_SPLIT) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 2 * H0; i < 2 * H1; ++i)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           int m = mbase + i * 16 + it * 4 + rq;
@@ -241,12 +246,12 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
       cols = *(const f32x4*)(g.ln_gamma + nbase + c * 4);
     }
     if constexpr (fold) {      // the bias is added behind the row scale: the raw accumulators are staged
-      colb = *(const f32x4*)(fc.xl + XLDS_BIAS + (fc.wn * 64 + c * 4) * 4);
-      cols = *(const f32x4*)(fc.xl + XLDS_COLSUM + (fc.wn * 64 + c * 4) * 4);
+      colb = *(const f32x4*)(fc.tab + XLDS_BIAS + (fc.wn * 64 + c * 4) * 4);
+      cols = *(const f32x4*)(fc.tab + XLDS_COLSUM + (fc.wn * 64 + c * 4) * 4);
     }
     constexpr bool stage_raw = fold || EPI == EPI_RESID32_LN;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 2 * H0; i < 2 * H1; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) *(f32x4*)(rows32(fr) + (j * 16 + fg * 4) * 4) = stage_raw ? acc[i][j] : acc[i][j] + bv[j];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -258,7 +263,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
         const size_t o = (size_t)m * N + nbase + c * 4;
         if constexpr (fold) {
           float fa, fcc;
-          fold_row_coef(g, fc.xl, fc.mrel + i * 16 + r, fa, fcc);
+          fold_row_coef(g, fc.tab, fc.mrel + i * 16 + r, fa, fcc);
           v = fa * v + (fcc * cols + colb);
         }
         if constexpr (EPI == EPI_RESID32) {
@@ -298,9 +303,10 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
             for (int e = 0; e < 4; ++e) { T h, l; split16<T>(rr[e], h, l); hi[e] = h; lo[e] = l; }
           }
           if (m < M) {
-            T* row = (T*)g.out + (size_t)m * (2 * N) + nbase + c * 4;
+            const size_t ldo = g.ldo ? (size_t)g.ldo : 2 * (size_t)N;
+            T* row = (T*)g.out + (size_t)m * ldo + nbase + c * 4;
             __builtin_nontemporal_store(hi, (v4*)row);
-            if (as_lo8) __builtin_nontemporal_store(lo8, (uint32_t*)((char*)g.out + (size_t)m * (4 * N) + 2 * N + nbase + c * 4));
+            if (as_lo8) __builtin_nontemporal_store(lo8, (uint32_t*)((char*)g.out + (size_t)m * (2 * ldo) + 2 * N + nbase + c * 4));
             else __builtin_nontemporal_store(lo, (v4*)(row + N));
             if constexpr (EPI == EPI_GELU_SPLIT) { if (g.out2) __builtin_nontemporal_store(u16, (v4*)((T*)g.out2 + o)); }
           }
@@ -328,12 +334,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   constexpr int A_IT = BM_ / 8 / NW, B_IT = BN / 8 / NW, LOADS = A_IT + B_IT;
   constexpr int ST_MIN_ = (WMF / 4) * ((epi_base(EPI) == EPI_STORE16 || epi_base(EPI) == EPI_GELU) ? 8 : 16);
   constexpr bool CAN_FOLD = epi_folds(EPI);
-  [[maybe_unused]] char* const xlds = smem + NS * STAGE;        // LayerNorm folding: XLDS_BYTES behind the ring (when launched with them)
+  [[maybe_unused]] char* const xlds = smem + NS * STAGE;        // LayerNorm folding: XLDS_BYTES(_WIDE) behind the ring (when launched with them)
+  [[maybe_unused]] char* const xtab = xlds + xlds_tab(g.fold_ntp);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = g.M, N = g.N, K = g.K;
-  const int lda = g.a_split ? 2 * K : K;
+  const int lda = g.lda ? g.lda : (g.a_split ? 2 * K : K);
   const int ldb = g.ldb ? g.ldb : K;
   const T* __restrict__ A = (const T*)g.A;
   const T* __restrict__ Bt = (const T*)g.Bt;
@@ -409,8 +416,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
         }
         // ... and the tile's slices of W gamma and b + W beta (BN floats each: the epilogue reads them with ds_read)
         const int n0 = (lt % tilesN) * BN + (lane < BN / 4 ? lane : BN / 4 - 1) * 4;
-        if (wave == NW - 1) glds16(g.fold_colsum + n0, xlds + XLDS_COLSUM);
-        if (wave == NW - 2) glds16(g.bias + n0, xlds + XLDS_BIAS);
+        if (wave == NW - 1) glds16(g.fold_colsum + n0, xtab + XLDS_COLSUM);
+        if (wave == NW - 2) glds16(g.bias + n0, xtab + XLDS_BIAS);
       }
     }
     lslot = lslot + 1 == NS ? 0 : lslot + 1;
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
     if constexpr (CAN_FOLD) {
       // LayerNorm folding: the rows' {rstd, -rstd * mean} once per tile (the partials landed with the last K-stage), then one
       // barrier; the epilogue reads 8 bytes per row instead of re-deriving them in every lane
-      if (tid < BM_) fold_build_coef(g, xlds, tid);
+      if (tid < BM_) fold_build_coef(g, xlds, xtab, tid);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -599,20 +606,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
       epilogue_store<T, EPI>(g, acc[hh], tm * BM_ + wm * (WMF * 16) + hh * 64, tn * BN + wn * 64, lane,
                              LinearRows<144>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE},
                              LinearRows<272>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE},
-                             FoldCtx{xlds, wm * (WMF * 16) + hh * 64, wn, WCN, MIXED ? 2 : (g.ln_split ? 1 : 0)});
+                             FoldCtx{xlds, xtab, wm * (WMF * 16) + hh * 64, wn, WCN, MIXED ? 2 : (g.ln_split ? 1 : 0)});
     MVLPT_TR(9);
     __builtin_amdgcn_s_barrier();
     if constexpr (EPI == EPI_RESID32_LN) {
-      // the tile's row partials: the WCN column blocks summed in a fixed order, one 8-byte slot per (row, N-tile); the region is
-      // rewritten by the next tile's epilogue, nk barriers from here
+      // the tile's row partials: one 8-byte slot per (row, 128 output columns) = the sum of two wave column blocks, whatever
+      // the tile geometry — the statistics a row gets (and the order they are summed in) do not depend on the geometry the
+      // launcher picks for the batch size (tests/test_hip_properties.py: a batch in two halves equals the whole bit for bit).
+      // The region is rewritten by the next tile's epilogue, nk barriers from here
       if (tid < BM_) {
         const int row = tm * BM_ + tid;
         if (row < M) {
           const float2* p = (const float2*)(xlds + (size_t)tid * WCN * 8);
-          float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-          for (int w = 0; w < WCN; ++w) { s1 += p[w].x; s2 += p[w].y; }
-          *(float2*)(g.ln_part + ((size_t)row * g.ln_ntp + tn) * 2) = float2{s1, s2};
+          for (int k = 0; k < WCN / 2; ++k)
+            *(float2*)(g.ln_part + ((size_t)row * g.ln_ntp + tn * (WCN / 2) + k) * 2) = float2{p[2 * k].x + p[2 * k + 1].x, p[2 * k].y + p[2 * k + 1].y};
         }
       }
     }
@@ -644,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_phased_kernel(GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool trail = wave >= NW / 2;
   const int M = g.M, N = g.N, K = g.K;
-  const int lda = g.a_split ? 2 * K : K;
+  const int lda = g.lda ? g.lda : (g.a_split ? 2 * K : K);
   const int ldb = g.ldb ? g.ldb : K;
   const T* __restrict__ A = (const T*)g.A;
   const T* __restrict__ Bt = (const T*)g.Bt;
@@ -766,7 +774,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_phased_kernel(GemmArgs g) {
     const int tm = t / tilesN, tn = t - tm * tilesN;
     epilogue_store<T, EPI>(g, acc, tm * BM_ + wm * 64, tn * BN + wn * 64, lane,
                            SlabRows<144>{smem + lslot * STAGE, wave, A_BYTES}, SlabRows<272>{smem + lslot * STAGE, wave, A_BYTES},
-                           FoldCtx{nullptr, 0, 0, 0, 0});     // (launch_one never sends a folded GEMM here)
+                           FoldCtx{nullptr, nullptr, 0, 0, 0, 0});     // (launch_one never sends a folded GEMM here)
     stores_pending = (tm + 1) * BM_ <= M;
   }
   if (!trail) __builtin_amdgcn_s_barrier();         // balance the extra barrier of the trailing group
@@ -786,16 +794,210 @@ static hipError_t launch_phased(const GemmArgs& g, hipStream_t s, hipEvent_t ea,
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------- producer / consumer variant
+// Problems with no more 128x128 tiles than compute units (the text tower at M = C*L ~ 7.7k rows, N = 512: 244 tiles) leave every
+// CU with ONE 4-wave workgroup, i.e. one wave per SIMD, and that wave issues everything itself: per K-stage 8 LDS-DMA instructions
+// (~80 issue cycles each), 16 fragment reads and 32 MFMAs (512 cycles) — measured 1 900 cycles per stage (K = 2048, mixed pair).
+// Here the tile gets EIGHT waves: waves 0-3 (2x2 blocks of 64x64, one per SIMD) only multiply, waves 4-7 (their SIMD partners)
+// only move data: they request K-stage f + 3 into the 4-deep ring (three stages in flight, as before), wait for their own pieces
+// of stage f with exact vmcnt counts and publish it with the stage barrier; the multiplying waves never touch vmcnt.
+//   RAW: stage f is waited for by its requesters in front of barrier f; the consumers read it behind that barrier.
+//   WAR: stage f + 3 goes to the slot of stage f - 1, whose readers arrive at barrier f only when they are done with it; the
+//        request is issued behind barrier f.
+// One tile per workgroup (grid = tiles <= compute units).  A K-split of the tile over two multiplying wave groups was built first
+// and measured 40 % SLOWER (text tower 4.29 -> 6.13 ms): its two 64-KiB double stages leave one stage of look-ahead, and these
+// under-filled GEMMs are bound by the latency of their L2 / Infinity-Cache reads (NOTES_experiments.md).
+template <typename T, int EPI, bool MIXED>
+__global__ __launch_bounds__(512, 1) void gemm_pc_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using v8 = typename Vec<T>::v8;
+  constexpr int BM_ = 128, BN = 128, NS = 4, LOADS = 8;
+  constexpr int A_BYTES = BM_ * BK * 2, STAGE = A_BYTES + BN * BK * 2;
+  [[maybe_unused]] char* const xlds = smem + NS * STAGE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool mover = wave >= 4;
+  const int w4 = wave & 3;
+  const int M = g.M, N = g.N, K = g.K;
+  const int tilesN = N / BN;
+  const int t = blockIdx.x;
+  const int tm = t / tilesN, tn = t - tm * tilesN;
+  const int m0 = tm * BM_, n0 = tn * BN;
+  const int nkb = K / BK, nk = MIXED ? nkb + nkb / 2 : (g.a_split ? 2 * nkb : nkb);
+  const int nk16 = MIXED ? nkb : nk;
+
+  if (mover) {
+    const int lda = g.lda ? g.lda : (g.a_split ? 2 * K : K);
+    const int ldb = g.ldb ? g.ldb : K;
+    const T* __restrict__ A = (const T*)g.A;
+    const T* __restrict__ Bt = (const T*)g.Bt;
+    const int srow = lane >> 3;
+    const int scol = ((lane & 7) ^ srow) * 8;
+    const T* ap[4];
+    const T* bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int ar = m0 + (i * 4 + w4) * 8 + srow; ar = ar < M ? ar : M - 1;
+      ap[i] = A + (size_t)ar * lda + scol;
+      const int br = n0 + (i * 4 + w4) * 8 + srow;
+      bp[i] = Bt + (size_t)br * ldb + scol;
+    }
+    auto issue = [&](int f) {
+      char* base = smem + (f & (NS - 1)) * STAGE;
+      const int bk = (f >= nkb && !MIXED) ? f - nkb : f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16(ap[i] + f * BK, base + (i * 4 + w4) * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16(bp[i] + bk * BK, base + A_BYTES + (i * 4 + w4) * 1024);
+    };
+#pragma unroll
+    for (int f = 0; f < NS - 1; ++f) if (f < nk) issue(f);
+    for (int f = 0; f < nk; ++f) {
+      // requested so far: stages 0 .. min(f + 2, nk - 1); stage f must have landed, the younger ones may stay in flight
+      const int younger = (nk - 1 - f) < 2 ? (nk - 1 - f) : 2;
+      if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (f + NS - 1 < nk) issue(f + NS - 1);
+    }
+    if constexpr (EPI == EPI_RESID32_LN) __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  const int wm = w4 >> 1, wn = w4 & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int a_off = (wm * 64 + fr) * 128;
+  const int b_off = A_BYTES + (wn * 64 + fr) * 128;
+  const int c0 = ((0 + fg) ^ (fr & 7)) * 16;
+  const int c1 = ((4 + fg) ^ (fr & 7)) * 16;
+  [[maybe_unused]] const int e0 = ((2 * fg) ^ (fr & 7)) * 16, e1 = ((2 * fg + 1) ^ (fr & 7)) * 16;
+  [[maybe_unused]] const int sc_w = 127 - g.w8_exp, sc_a = 127 - Lo8<T>::EXP;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int f = 0; f < nk16; ++f) {
+    __builtin_amdgcn_s_barrier();
+    const char* base = smem + (f & (NS - 1)) * STAGE;
+    v8 bf[2][4], af[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[0][j] = *(const v8*)(base + b_off + j * 2048 + c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[0][i] = *(const v8*)(base + a_off + i * 2048 + c0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = mfma16<T>(bf[ks][0], af[ks][0], acc[0][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == 0) {      // the second k-step's fragments travel under the first one's MFMAs
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[1][j] = *(const v8*)(base + b_off + j * 2048 + c1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[1][i] = *(const v8*)(base + a_off + i * 2048 + c1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (i == 0 && j == 0) continue;
+          acc[i][j] = mfma16<T>(bf[ks][j], af[ks][i], acc[i][j]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if constexpr (MIXED)
+  for (int f = nk16; f < nk; ++f) {
+    __builtin_amdgcn_s_barrier();
+    const char* base = smem + (f & (NS - 1)) * STAGE;
+    i32x8 b8[4], a8[2];
+    auto ld8 = [&](int off) -> i32x8 {
+      const i32x4 x = *(const i32x4*)(base + off + e0), y = *(const i32x4*)(base + off + e1);
+      return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b8[j] = ld8(b_off + j * 2048);
+    a8[0] = ld8(a_off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_lo8(b8[0], a8[i & 1], acc[i][0], sc_w, sc_a);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < 4) a8[(i + 1) & 1] = ld8(a_off + (i + 1) * 2048);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 1; j < 4; ++j) mfma_lo8(b8[j], a8[i & 1], acc[i][j], sc_w, sc_a);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_lo8_fence();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // epilogue scratch: the slot of the last stage but one (every request has landed; the four multiplying waves only sync with
+  // each other through their own reads, so each waits for its partners with the producer barrier below when there is one)
+  char* const scr = smem + ((nk + 1) & (NS - 1)) * STAGE + w4 * EPI_SCRATCH_PER_WAVE;
+  const FoldCtx fc{xlds, nullptr, wm * 64, wn, 2, MIXED ? 2 : (g.ln_split ? 1 : 0)};
+  epilogue_store<T, EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, lane, LinearRows<144>{scr}, LinearRows<272>{scr}, fc);
+  if constexpr (EPI == EPI_RESID32_LN) {
+    __builtin_amdgcn_s_barrier();
+    if (tid < BM_) {
+      const int row = m0 + tid;
+      if (row < M) {
+        const float2* pp = (const float2*)(xlds + (size_t)tid * 2 * 8);
+        *(float2*)(g.ln_part + ((size_t)row * g.ln_ntp + tn) * 2) = float2{pp[0].x + pp[1].x, pp[0].y + pp[1].y};
+      }
+    }
+  }
+}
+
+template <typename T, int EPI, bool MIXED>
+static hipError_t launch_pc_m(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  constexpr int LDS = 4 * (128 + 128) * BK * 2 + XLDS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_pc_kernel<T, EPI, MIXED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int tiles = ((g.M + 127) / 128) * (g.N / 128);
+  hipExtLaunchKernelGGL((gemm_pc_kernel<T, EPI, MIXED>), dim3(tiles), dim3(512), LDS, s, ea, eb, 0, g);
+  return hipGetLastError();
+}
+template <typename T, int EPI>
+static hipError_t launch_pc(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  if constexpr (epi_folds(EPI)) return hipErrorInvalidValue;
+  else {
+    constexpr int BE = epi_base(EPI);
+    if constexpr (BE == EPI_RESID32 || BE == EPI_RESID32_LN || BE == EPI_STORE32 || BE == EPI_GELU_SPLIT || BE == EPI_GELUBWD_SPLIT || BE == EPI_STORE_SPLIT) {
+      if (g.a_split == 2) return launch_pc_m<T, EPI, true>(g, s, ea, eb);
+    } else if (g.a_split == 2) return hipErrorInvalidValue;
+    return launch_pc_m<T, EPI, false>(g, s, ea, eb);
+  }
+}
+// the producer / consumer kernel takes the problem: one tile per workgroup, no more tiles than compute units, no consumer-side
+// LayerNorm folding
+template <int EPI>
+static bool pc_takes(const GemmArgs& g, long cus) {
+  if (epi_folds(EPI)) return false;
+  return (long)((g.M + 127) / 128) * (g.N / 128) <= cus;
+}
+
 template <typename T, int EPI, int BM_, int BN_, int NW, int NS, bool MIXED>
 static hipError_t launch_geo_m(const GemmArgs& g, int wg_per_cu, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
   constexpr int LDS = NS * (BM_ + BN_) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + XLDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS + (LDS + XLDS_BYTES_WIDE <= 160 * 1024 ? XLDS_BYTES_WIDE : XLDS_BYTES));
     attr_set = true;
   }
   // LayerNorm folding: 16 KiB behind the ring (the consumer's row partials / the producer's per-tile column-block sums)
-  const int lds = LDS + ((epi_folds(EPI) || EPI == EPI_RESID32_LN) ? XLDS_BYTES : 0);
+  const int lds = LDS + (epi_folds(EPI) ? xlds_bytes(g.fold_ntp) : (EPI == EPI_RESID32_LN ? XLDS_BYTES : 0));
+  if (lds > 160 * 1024) return hipErrorInvalidValue;      // (launch_one keeps 8-slot consumers off the 3-deep 256x128 ring)
   int cus = stream_cus(s);
 #ifdef MVLPT_DEBUG_CUS
   if (getenv("MVLPT_DBG_CUS")) cus = atoi(getenv("MVLPT_DBG_CUS"));      // CU-scaling measurement, debug builds only
@@ -821,7 +1023,7 @@ static hipError_t launch_geo(const GemmArgs& g, int wg_per_cu, hipStream_t s, hi
 template <int EPI>
 static GemmArgs row_slice(const GemmArgs& g, int m_lo, int rows) {
   GemmArgs r = g;
-  const size_t ok = (size_t)m_lo * g.K * (g.a_split ? 2 : 1), on = (size_t)m_lo * g.N;
+  const size_t ok = (size_t)m_lo * (g.lda ? (size_t)g.lda : (size_t)g.K * (g.a_split ? 2 : 1)), on = (size_t)m_lo * g.N;
   constexpr int BE = epi_base(EPI);
   constexpr size_t OB = (BE == EPI_RESID32 || BE == EPI_RESID32_LN || BE == EPI_STORE32 || BE == EPI_GELU_SPLIT || BE == EPI_GELUBWD_SPLIT || BE == EPI_STORE_SPLIT) ? 4 : 2;
   r.A = (const char*)g.A + ok * 2;
@@ -862,7 +1064,13 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
     *tile_m = 256; *tile_n = 256;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
   }
-  if (geo >= 1 && r15) {
+  // (a folded consumer with 8-slot rows needs 20 KiB behind its ring: the 3-deep 256x128 ring has 16 left -> 256x256 or 128x128)
+  const bool wide_fold = epi_folds(EPI) && g.fold_ntp > 6;
+  if (geo >= 2 && wide_fold && r15 && g.N % 256 == 0) {
+    *tile_m = 256; *tile_n = 256;
+    return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
+  }
+  if (geo >= 1 && r15 && !wide_fold) {
     *tile_m = 256; *tile_n = 128;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 128, 8, 3>(g, 1, s, ea, eb);
   }
@@ -872,6 +1080,12 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   // (its 128 KiB workgroups cannot share a CU with the image-tower kernels they overlap with) -> off.  Round 2 (split operands
   // double every K of the text tower): tower alone 5.57 -> 5.10 ms, overlapped step 15.22 -> 15.00 ms -> on.
   const long t_small = (long)((g.M + 127) / 128) * (g.N / 128);
+  // dedicated data-movement waves (gemm_pc_kernel above): split operands 1 (default), every operand kind 2, off 0
+  static const int pcw = getenv("MVLPT_GEMM_PC") ? atoi(getenv("MVLPT_GEMM_PC")) : 1;
+  if (pcw && (g.a_split || pcw >= 2) && pc_takes<EPI>(g, cus)) {
+    *tile_m = 128; *tile_n = 128;
+    return ea == (hipEvent_t)-1 ? hipSuccess : launch_pc<T, EPI>(g, s, ea, eb);
+  }
   if (deep && g.a_split && t_small <= cus) {
     *tile_m = 128; *tile_n = 128;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 128, 128, 4, 4>(g, 1, s, ea, eb);
@@ -953,6 +1167,8 @@ hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hip
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0 || (g.N % 128) != 0) return hipErrorInvalidValue;
   if (g.a_split == 2 && ((g.K % 128) != 0 || g.ldb < g.K + g.K / 2)) return hipErrorInvalidValue;
   if (g.ldb && (g.ldb < g.K || (g.ldb % 8) != 0)) return hipErrorInvalidValue;
+  if (g.lda && (g.lda < (g.a_split ? 2 : 1) * g.K || (g.lda % 8) != 0)) return hipErrorInvalidValue;
+  if (g.ldo && (g.ldo < 2 * g.N || (g.ldo % 8) != 0 || !(epi == EPI_GELU_SPLIT || epi == EPI_GELUBWD_SPLIT || epi == EPI_STORE_SPLIT))) return hipErrorInvalidValue;
   if ((epi == EPI_RESID32 || epi == EPI_RESID32_LN) && !g.resid) return hipErrorInvalidValue;
   if (epi == EPI_RESID32_LN && (!g.ln_gamma || !g.ln_x16 || !g.ln_part || g.ln_ntp <= 0 || (g.ln_ntp & 1))) return hipErrorInvalidValue;
   if (g.fold_part) {

@@ -2,6 +2,7 @@
 // assembly with the learnable prompt rows spliced in, prompt-gradient reductions, casts / weight packing, and
 // the fp32 head (cosine logits + cross-entropy).  All coalesced along the feature dimension, 16-byte
 // accesses where the layout allows; reductions use wavefront shuffles.
+#include <type_traits>
 #include "kernels.h"
 
 namespace mvlpt {
@@ -203,8 +204,36 @@ __global__ void patchify_vec_kernel(const float* __restrict__ img, T* __restrict
     *(typename Vec<T>::v8*)(out + row * Kp + col) = w;
   }
 }
+// fast path: 16-bit image of the compute type, P % 8 == 0: a pure copy of 16-byte chunks.  One block per (image, patch row):
+// its 3 x P image rows are read as one coalesced stream into LDS and leave as whole patch rows (Kp * 2 contiguous bytes each)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void patchify16_kernel(const u32x4* __restrict__ img, u32x4* __restrict__ out, int R, int P, int Kp) {
+  extern __shared__ u32x4 pf_sm[];
+  const int G = R / P, RC = R / 8, PC = P / 8;
+  const int b = blockIdx.x / G, gy = blockIdx.x - b * G;
+  const int n = 3 * P * RC;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int c = i / (P * RC), rem = i - c * (P * RC), ky = rem / RC, xc = rem - ky * RC;
+    pf_sm[i] = __builtin_nontemporal_load(img + (((size_t)b * 3 + c) * R + gy * P + ky) * RC + xc);
+  }
+  __syncthreads();
+  const int KC = Kp / 8, KV = 3 * P * PC;
+  for (int i = threadIdx.x; i < G * KC; i += 256) {
+    const int gx = i / KC, cb = i - gx * KC;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (cb < KV) {
+      const int c = cb / (P * PC), rem = cb - c * (P * PC), ky = rem / PC, kc = rem - ky * PC;
+      v = pf_sm[(c * P + ky) * RC + gx * PC + kc];
+    }
+    out[((size_t)(b * G + gy) * G + gx) * KC + cb] = v;
+  }
+}
 template <typename T>
 static hipError_t patchify_t(const void* image, int image_dtype, T* out, int B, int R, int P, int Kp, hipStream_t s) {
+  if (image_dtype == (sizeof(T) == 2 && std::is_same<T, f16>::value ? DT_F16 : DT_BF16) && P % 8 == 0 && R % 8 == 0 && 3 * P * (R / 8) * 16 <= 65536) {
+    hipLaunchKernelGGL(patchify16_kernel, dim3(B * (R / P)), dim3(256), 3 * P * (R / 8) * 16, s, (const u32x4*)image, (u32x4*)out, R, P, Kp);
+    return hipGetLastError();
+  }
   if (image_dtype == DT_F32 && P % 8 == 0 && R % 4 == 0) {
     const size_t n8v = (size_t)B * (R / P) * (R / P) * (Kp / 8);
     const int gridv = (int)((n8v + 255) / 256 < 16384 ? (n8v + 255) / 256 : 16384);

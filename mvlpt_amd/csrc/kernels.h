@@ -57,17 +57,22 @@ struct GemmArgs {
   int ldb = 0;         // Bt row pitch in 16-bit elements (0: K)
   int w8_exp = 0;      // a_split == 2: exponent of the weight's fp8 plane
   int out_lo8 = 0;     // EPI_GELU_SPLIT / EPI_GELUBWD_SPLIT: store the pair as [hi | lo8] (mixed pair) instead of [hi | lo]
+  // Row pitches in 16-bit elements (0: dense).  lda: rows of A (dense: K, or 2K with a_split); ldo: rows of `out` for the pair-producing
+  // epilogues 5 / 6 / 7 (dense: 2N).  A pitch that is a multiple of 4 KiB puts the same K-stage of every row on the same memory
+  // channels (M = 7 700, K = 2048 pair rows of 8 KiB: 56 vs 36 us next to K = 1920 / 2176, profiles/r04_pitch_probe.txt): the engine
+  // pads such rows by 128 bytes.
+  int lda = 0, ldo = 0;
   // ---- LayerNorm folding: LN(x) W^T = rstd_r * ((x * gamma) W^T)[r,n] - rstd_r * mean_r * (W gamma)[n] + (W beta)[n], so the
   // GEMM in front of a LayerNorm hands the un-normalised row to the GEMM behind it and the LayerNorm pass (one read of the fp32
   // residual stream + one 16-bit write per LayerNorm) disappears.  No atomics, no extra launch: every output tile owns its slots.
   // Producer (EPI_RESID32_LN): besides out32 = acc + bias + resid32 the epilogue stores ln_x16 = round16(out32 * ln_gamma) — the A
-  // operand of the consumer, format ln_split: 0 [M,N], 1 hi|lo pair [M,2N], 2 mixed pair (same pitch) — and, per row and N-tile
-  // tn, the partial sums {sum out32, sum out32^2} over the tile's columns at ln_part[(row * ln_ntp + tn) * 2] (fp32 pairs).
+  // operand of the consumer, format ln_split: 0 [M,N], 1 hi|lo pair [M,2N], 2 mixed pair (same pitch) — and, per row and block j of
+  // 128 output columns (independent of the tile geometry), the partial sums {sum out32, sum out32^2} at ln_part[(row * ln_ntp + j) * 2].
   const float* ln_gamma = nullptr;
   void* ln_x16 = nullptr;
   int ln_split = 0;
   float* ln_part = nullptr;
-  int ln_ntp = 0;               // slots per row (>= number of N-tiles of this launch, even)
+  int ln_ntp = 0;               // slots per row (>= N / 128, even)
   // Consumer (EPI_STORE16 / EPI_GELU / EPI_STORE_SPLIT / EPI_GELU_SPLIT with fold_part != null): A holds round16(x * gamma);
   // mean / rstd of row r are rebuilt from its fold_nt partials (summed in slot order: deterministic) and the epilogue computes
   // rstd_r * acc - rstd_r * mean_r * fold_colsum[n] + bias[n], with fold_colsum = W gamma and bias = b + W beta precomputed
@@ -80,7 +85,7 @@ struct GemmArgs {
   long long* trace = nullptr;   // debug builds only: per-wave (point id << 56 | s_memtime) records of workgroup 0
 #endif
 };
-// N-tile width the launcher picks for this problem on this stream (the producer's partial-slot count is N / it)
+// N-tile width the launcher picks for this problem on this stream
 int gemm_tile_n(int dtype, int epi, const GemmArgs& g, hipStream_t s);
 // ev_start/ev_stop (optional): recorded by the dispatch itself (hipExtLaunchKernelGGL): kernel-exact timing with no
 // extra marker packets on the stream.

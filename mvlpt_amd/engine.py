@@ -505,7 +505,7 @@ def op_fold_vectors(W16: torch.Tensor, K: int, gamma, beta, b):
     return cs, b2
 
 
-def op_gemm_ln_producer(A, Bt, bias, resid, gamma, a_split=0, x16_split=0, ldb=0, w8_exp=0, ntp=6):
+def op_gemm_ln_producer(A, Bt, bias, resid, gamma, a_split=0, x16_split=0, ldb=0, w8_exp=0, ntp=8):
     """-> (out32 [M,N], x16 (format x16_split), part [M, ntp, 2], nt)."""
     dtype = A.dtype
     M = A.shape[0]

@@ -43,7 +43,8 @@ def test_cast_mixed_carries_the_value(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 256, 256), (77, 128, 512), (1000, 768, 3072), (4096, 2304, 768), (7700, 512, 2048)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 256, 256), (77, 128, 512), (1000, 768, 3072), (4096, 2304, 768), (7700, 512, 2048),
+                                   (7700, 512, 512), (7700, 512, 1536), (250, 768, 3072)])     # one-tile-per-CU problems: the kernel with dedicated data-movement waves
 def test_gemm_mixed_operand(dtype, M, N, K):
     E = _eng()
     g = torch.Generator().manual_seed(M + N + K + 1)
@@ -157,3 +158,19 @@ def test_attention32_mixed_outputs(L, causal):
             continue
         e = relerr(got[:, i * d:(i + 1) * d], r_i)
         assert e < 3 * PAIR_TOL[dtype], f"d{nm}: {e}"
+
+
+def test_attention32_persistent_mixed_output():
+    """The persistent resident forward (enough heads to give every workgroup several) writes the same hi plane and lse in both output
+    formats, and the mixed O carries the pair's value to the mixed pair's resolution."""
+    E = _eng()
+    N, H, L = 43, 12, 205
+    d = H * 64
+    dtype = torch.float16
+    qkv = torch.randn(N * L, 3 * d, generator=torch.Generator().manual_seed(77))
+    qp = E.split_pair(qkv.cuda(), dtype)
+    o_pair, lse = E.op_attention32_fwd_pair(qp, N, L, H, False)
+    o_mix, lse_m = E.op_attention32_fwd_mixed(qp, N, L, H, False)
+    assert bool(torch.equal(lse, lse_m)) and bool(torch.equal(o_pair[:, :d], o_mix[:, :d]))
+    assert relerr(E.join_mixed(o_mix), E.join_pair(o_pair)) < PAIR_TOL[dtype]
+

@@ -175,7 +175,8 @@ SPLIT_TOL = {torch.float16: 3e-6, torch.bfloat16: 6e-5}    # pair = 22 / 16 sign
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (391, 512, 256), (77, 128, 128), (1000, 768, 3072), (4096, 2304, 768), (30000, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (391, 512, 256), (77, 128, 128), (1000, 768, 3072), (4096, 2304, 768), (30000, 768, 768),
+                                   (7700, 512, 512), (7700, 512, 2048)])      # dedicated data-movement waves
 def test_gemm_split_operand(dtype, M, N, K):
     E = _eng()
     g = torch.Generator().manual_seed(M + N + K + 1)
@@ -283,6 +284,32 @@ def test_attention32_fwd_bwd(L, causal):
         ref1 = torch.cat([t.permute(0, 2, 1, 3).reshape(N * L, d) for t in (dq, dk, dv)], dim=-1)
         got1 = E.join_pair(E.op_attention32_bwd_pair(qp, o1, E.split_pair(d_cls.reshape(N * L, d).cuda(), torch.float16), lse1, N, L, H, False))
         assert bool(torch.isfinite(got1).all()) and relerr(got1, ref1) < 1e-5
+
+
+@pytest.mark.parametrize("N,H,L", [(43, 12, 205), (64, 8, 197), (90, 6, 100), (171, 3, 81)])
+def test_attention32_fwd_persistent_heads(N, H, L):
+    """The persistent resident forward (80 < L <= 208, at least two (sequence, head) items per compute unit: each workgroup walks
+    several heads and prefetches the next one's K / V through its three-buffer rotation) against the fp32 oracle, a ragged number of
+    heads per workgroup included, for the pair and the mixed-pair output; two runs are bit-identical."""
+    E = _eng()
+    d = H * 64
+    g = torch.Generator().manual_seed(N * 1000 + L)
+    qkv = torch.randn(N * L, 3 * d, generator=g)
+    q, k, v, o, p = _attn_ref(qkv, N, L, H, False)
+    o_ref = o.permute(0, 2, 1, 3).reshape(N * L, d)
+    out2, lse = E.op_attention32_fwd(qkv.cuda(), N, L, H, False)
+    assert relerr(E.join_pair(out2), o_ref) < 5e-6
+    s = torch.matmul(q, k.transpose(-1, -2)) / 8.0
+    assert float((lse.cpu() - torch.logsumexp(s, -1).reshape(-1)).abs().max()) < 1e-5
+    again, lse2 = E.op_attention32_fwd(qkv.cuda(), N, L, H, False)
+    assert torch.equal(again, out2) and torch.equal(lse2, lse)
+    # the backward consumes what the persistent forward left (out pair, lse)
+    dout = torch.randn(N * L, d, generator=g)
+    do = dout.reshape(N, L, H, 64).permute(0, 2, 1, 3)
+    dq, dk, dv = O.attention_bwd(do, q, k, v, p)
+    dqkv_ref = torch.cat([t.permute(0, 2, 1, 3).reshape(N * L, d) for t in (dq, dk, dv)], dim=-1)
+    dqkv = E.join_pair(E.op_attention32_bwd(qkv.cuda(), out2, dout.cuda(), lse, N, L, H, False))
+    assert relerr(dqkv.cpu(), dqkv_ref) < 1e-5
 
 
 def test_attention32_is_not_transposed():
