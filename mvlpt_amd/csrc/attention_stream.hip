@@ -90,15 +90,18 @@ __global__ __launch_bounds__(256) void attn_fwd_stream_kernel(AttnArgs a, int nq
       s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       s[u] = mfma16<T>(frag_rows<T>(sK, u, 0, fr, fg), q0, s[u]);
       s[u] = mfma16<T>(frag_rows<T>(sK, u, 1, fr, fg), q1, s[u]);
+      // raw scores (the scale sits in the exponent's FMA); the mask only where a key can be >= L or on the causal diagonal
+      if (CAUSAL || c * CK + (u + 1) * 16 > L) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = c * CK + u * 16 + fg * 4 + r;
-        const bool ok = key < L && (!CAUSAL || key <= qrow);
-        s[u][r] = ok ? s[u][r] * SC : -INFINITY;
-        mx = fmaxf(mx, s[u][r]);
+        for (int r = 0; r < 4; ++r) {
+          const int key = c * CK + u * 16 + fg * 4 + r;
+          const bool ok = key < L && (!CAUSAL || key <= qrow);
+          s[u][r] = ok ? s[u][r] : -INFINITY;
+        }
       }
+      mx = fmaxf(mx, fmaxf(fmaxf(s[u][0], s[u][1]), fmaxf(s[u][2], s[u][3])));
     }
-    mx = quad_max(mx);
+    mx = quad_max(mx) * SC;
     const float mnew = fmaxf(mrun, mx);                         // finite from chunk 0 on (key 0 is never masked)
     const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
     mrun = mnew;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_fwd_stream_kernel(AttnArgs a, int nq
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s[u][r] = __builtin_amdgcn_exp2f(s[u][r] - mnew); sum += s[u][r]; }
+      for (int r = 0; r < 4; ++r) { s[u][r] = __builtin_amdgcn_exp2f(fmaf(s[u][r], SC, -mnew)); sum += s[u][r]; }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const v8 pf = pack8<T>(s[2 * kb], s[2 * kb + 1]);
