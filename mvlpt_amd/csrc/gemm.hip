@@ -986,6 +986,249 @@ static bool pc_takes(const GemmArgs& g, long cus) {
   return (long)((g.M + 127) / 128) * (g.N / 128) <= cus;
 }
 
+// ---------------------------------------------------------------------------------------------- persistent, with movers
+// The 256x128 geometry (GEMMs with 1.5 .. 4 rounds of tiles: out-projection of the image tower, the text tower's N = 2048 GEMMs)
+// spends as many issue cycles on its LDS-DMA as on its MFMAs: 48 KiB per K-stage are 6 DMA instructions per wave (~450 cycles)
+// against 512 cycles of MFMA per wave, and a stage takes 2 800 cycles for 1 024 of matrix work per SIMD (tile timelines,
+// profiles/r04_gemm_tile_timelines.txt).  Same split of labour as gemm_pc_kernel, persistent: TWELVE waves — 0-7 (4x2 blocks of
+// 64x64, two per SIMD) only read fragments and multiply, 8-11 (one per SIMD) walk the workgroup's tile list two K-stages ahead of
+// them (3-deep ring, across tile boundaries: the first two stages of the next tile land under the epilogue) and publish every stage
+// with exact vmcnt waits + the stage barrier.  64x64 accumulator blocks keep the kernel under the 168 VGPRs three waves per SIMD
+// leave.  Tile end: barrier (the last stage's slot is free: epilogue scratch), epilogue, barrier (the movers may overwrite it).
+// LayerNorm folding: the movers bring a consumer tile's row partials and column vectors with its last K-stage (the same number
+// of instructions each, so the counted waits stay compile-time constants); rows of up to 6 slots (d <= 768).
+template <typename T, int EPI, bool MIXED>
+__global__ __launch_bounds__(768, 1) void gemm_pcp_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using v8 = typename Vec<T>::v8;
+  constexpr int BM_ = 256, BN = 128, NS = 3, NCW = 8, LOADS = 12;
+  constexpr int A_BYTES = BM_ * BK * 2, STAGE = A_BYTES + BN * BK * 2;
+  constexpr bool CAN_FOLD = epi_folds(EPI);
+  [[maybe_unused]] char* const xlds = smem + NS * STAGE;
+  [[maybe_unused]] char* const xtab = xlds + xlds_tab(g.fold_ntp);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = g.M, N = g.N, K = g.K;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int tilesN = N / BN;
+  const int ntiles = ((M + BM_ - 1) / BM_) * tilesN;
+  const int gq = G >> 3, gr = G & 7, xcd = b & 7;
+  const int b_remap = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (b >> 3);
+  auto tile_of = [&](int round) -> int {
+    const int base = round * G;
+    return base + ((base + G <= ntiles) ? b_remap : b);
+  };
+  const int nkb = K / BK, nk = MIXED ? nkb + nkb / 2 : (g.a_split ? 2 * nkb : nkb);
+  const int nk16 = MIXED ? nkb : nk;
+  if (tile_of(0) >= ntiles) return;
+
+  if (wave >= NCW) {
+    // ------------------------------------------------------------------------------------------ data movement
+    const int w4 = wave - NCW;
+    const int lda = g.lda ? g.lda : (g.a_split ? 2 * K : K);
+    const int ldb = g.ldb ? g.ldb : K;
+    const T* __restrict__ A = (const T*)g.A;
+    const T* __restrict__ Bt = (const T*)g.Bt;
+    const int srow = lane >> 3;
+    const int scol = ((lane & 7) ^ srow) * 8;
+    const T* ap[8];
+    const T* bp[4];
+    int lround = 0, lt = tile_of(0), lkt = 0, lslot = 0;
+    auto set_ptrs = [&](int t) {
+      const int m0 = (t / tilesN) * BM_, n0 = (t % tilesN) * BN;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int ar = m0 + (i * 4 + w4) * 8 + srow; ar = ar < M ? ar : M - 1;
+        ap[i] = A + (size_t)ar * lda + scol;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int br = n0 + (i * 4 + w4) * 8 + srow;
+        bp[i] = Bt + (size_t)br * ldb + scol;
+      }
+    };
+    set_ptrs(lt);
+    const int cpr = g.fold_ntp >> 1;                 // CAN_FOLD: 16-byte chunks of partials per row = extra DMA instructions per mover
+    // -> 0 nothing left to request, 1 a plain stage (LOADS instructions), 2 a tile's last stage with the folding extras
+    auto issue = [&]() -> int {
+      if (lt >= ntiles) return 0;
+      char* base = smem + lslot * STAGE;
+      const int bk = ((lkt >= nkb && !MIXED) ? lkt - nkb : lkt) * BK;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) glds16(ap[i] + lkt * BK, base + (i * 4 + w4) * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16(bp[i] + bk, base + A_BYTES + (i * 4 + w4) * 1024);
+      int kind = 1;
+      if constexpr (CAN_FOLD) {
+        if (lkt == nk - 1) {
+          kind = 2;
+          const long first = (long)(lt / tilesN) * BM_ * cpr, last = (long)M * cpr - 1;
+          for (int j = 0; j < cpr; ++j) {
+            const int q0 = (w4 * cpr + j) * 64;
+            long q = first + q0 + lane; q = q < last ? q : last;
+            glds16(g.fold_part + q * 4, xlds + q0 * 16);
+          }
+          const int n0 = (lt % tilesN) * BN + (lane < BN / 4 ? lane : BN / 4 - 1) * 4;
+          if (w4 & 1) glds16(g.bias + n0, xtab + XLDS_BIAS);          // movers 1, 3 (the same bytes twice: harmless)
+          else glds16(g.fold_colsum + n0, xtab + XLDS_COLSUM);        // movers 0, 2
+        }
+      }
+      lslot = lslot + 1 == NS ? 0 : lslot + 1;
+      if (++lkt == nk) {
+        lkt = 0;
+        lt = tile_of(++lround);
+        if (lt < ntiles) set_ptrs(lt);
+      }
+      return kind;
+    };
+    (void)issue();
+    int ahead = issue();                               // kind of the one stage requested beyond the stage waited for next
+    for (int round = 0; tile_of(round) < ntiles; ++round) {
+      for (int f = 0; f < nk; ++f) {
+        // the stage the multiplying waves take next has landed; the one behind it may stay in flight (vmcnt retires in order)
+        if (ahead == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else if (cpr == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + 4) : "memory");
+        else if (cpr == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + 3) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");          // (more extras than counted: waits for some of them too)
+        __builtin_amdgcn_s_barrier();
+        ahead = issue();                               // into the slot of the stage consumed before this barrier
+      }
+      __builtin_amdgcn_s_barrier();                    // tile end: the multiplying waves take the last slot as scratch ...
+      if constexpr (CAN_FOLD) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();                    // ... and give it back
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------------------------------- multiplication
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int a_off = (wm * 64 + fr) * 128;
+  const int b_off = A_BYTES + (wn * 64 + fr) * 128;
+  const int c0 = ((0 + fg) ^ (fr & 7)) * 16;
+  const int c1 = ((4 + fg) ^ (fr & 7)) * 16;
+  [[maybe_unused]] const int e0 = ((2 * fg) ^ (fr & 7)) * 16, e1 = ((2 * fg + 1) ^ (fr & 7)) * 16;
+  [[maybe_unused]] const int sc_w = 127 - g.w8_exp, sc_a = 127 - Lo8<T>::EXP;
+  int slot = 0;
+  for (int round = 0;; ++round) {
+    const int t = tile_of(round);
+    if (t >= ntiles) break;
+    const int tm = t / tilesN, tn = t - tm * tilesN;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int last_slot = 0;
+    for (int f = 0; f < nk16; ++f) {
+      __builtin_amdgcn_s_barrier();
+      const char* base = smem + slot * STAGE;
+      last_slot = slot;
+      slot = slot + 1 == NS ? 0 : slot + 1;
+      v8 bf[2][4], af[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[0][j] = *(const v8*)(base + b_off + j * 2048 + c0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[0][i] = *(const v8*)(base + a_off + i * 2048 + c0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = mfma16<T>(bf[ks][0], af[ks][0], acc[0][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[1][j] = *(const v8*)(base + b_off + j * 2048 + c1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[1][i] = *(const v8*)(base + a_off + i * 2048 + c1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (i == 0 && j == 0) continue;
+            acc[i][j] = mfma16<T>(bf[ks][j], af[ks][i], acc[i][j]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if constexpr (MIXED)
+    for (int f = nk16; f < nk; ++f) {
+      __builtin_amdgcn_s_barrier();
+      const char* base = smem + slot * STAGE;
+      last_slot = slot;
+      slot = slot + 1 == NS ? 0 : slot + 1;
+      i32x8 b8[4], a8[2];
+      auto ld8 = [&](int off) -> i32x8 {
+        const i32x4 x = *(const i32x4*)(base + off + e0), y = *(const i32x4*)(base + off + e1);
+        return __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b8[j] = ld8(b_off + j * 2048);
+      a8[0] = ld8(a_off);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_lo8(b8[0], a8[i & 1], acc[i][0], sc_w, sc_a);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < 4) a8[(i + 1) & 1] = ld8(a_off + (i + 1) * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) mfma_lo8(b8[j], a8[i & 1], acc[i][j], sc_w, sc_a);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mfma_lo8_fence();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                      // every multiplying wave is done with the last stage: its slot is scratch
+    if constexpr (CAN_FOLD) {
+      if (tid < BM_) fold_build_coef(g, xlds, xtab, tid);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    epilogue_store<T, EPI>(g, acc, tm * BM_ + wm * 64, tn * BN + wn * 64, lane,
+                           LinearRows<144>{smem + last_slot * STAGE + wave * EPI_SCRATCH_PER_WAVE},
+                           LinearRows<272>{smem + last_slot * STAGE + wave * EPI_SCRATCH_PER_WAVE},
+                           FoldCtx{xlds, xtab, wm * 64, wn, 2, MIXED ? 2 : (g.ln_split ? 1 : 0)});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (EPI == EPI_RESID32_LN) {
+      if (tid < BM_) {
+        const int row = tm * BM_ + tid;
+        if (row < M) {
+          const float2* pp = (const float2*)(xlds + (size_t)tid * 2 * 8);
+          *(float2*)(g.ln_part + ((size_t)row * g.ln_ntp + tn) * 2) = float2{pp[0].x + pp[1].x, pp[0].y + pp[1].y};
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int EPI, bool MIXED>
+static hipError_t launch_pcp_m(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  constexpr int LDS = 3 * (256 + 128) * BK * 2 + XLDS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_pcp_kernel<T, EPI, MIXED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int cus = stream_cus(s);
+  const int tiles = ((g.M + 255) / 256) * (g.N / 128);
+  hipExtLaunchKernelGGL((gemm_pcp_kernel<T, EPI, MIXED>), dim3(tiles < cus ? tiles : cus), dim3(768), LDS, s, ea, eb, 0, g);
+  return hipGetLastError();
+}
+template <typename T, int EPI>
+static hipError_t launch_pcp(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  constexpr int BE = epi_base(EPI);
+  if constexpr (BE == EPI_RESID32 || BE == EPI_RESID32_LN || BE == EPI_STORE32 || BE == EPI_GELU_SPLIT || BE == EPI_GELUBWD_SPLIT || BE == EPI_STORE_SPLIT) {
+    if (g.a_split == 2) return launch_pcp_m<T, EPI, true>(g, s, ea, eb);
+  } else if (g.a_split == 2) return hipErrorInvalidValue;
+  return launch_pcp_m<T, EPI, false>(g, s, ea, eb);
+}
+
 template <typename T, int EPI, int BM_, int BN_, int NW, int NS, bool MIXED>
 static hipError_t launch_geo_m(const GemmArgs& g, int wg_per_cu, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
   constexpr int LDS = NS * (BM_ + BN_) * BK * 2;
@@ -1069,6 +1312,12 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   if (geo >= 2 && wide_fold && r15 && g.N % 256 == 0) {
     *tile_m = 256; *tile_n = 256;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
+  }
+  // 256x128 with data-movement waves (gemm_pcp_kernel): 1 on (default), 0 the self-serving 8-wave kernel
+  static const int pcp = getenv("MVLPT_GEMM_PCP") ? atoi(getenv("MVLPT_GEMM_PCP")) : 1;
+  if (geo >= 1 && r15 && !wide_fold && pcp && (!epi_folds(EPI) || (g.fold_ntp == 4 || g.fold_ntp == 6))) {
+    *tile_m = 256; *tile_n = 128;
+    return ea == (hipEvent_t)-1 ? hipSuccess : launch_pcp<T, EPI>(g, s, ea, eb);
   }
   if (geo >= 1 && r15 && !wide_fold) {
     *tile_m = 256; *tile_n = 128;
