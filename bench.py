@@ -431,7 +431,7 @@ def main():
             # would count concurrent stretches twice).  Both are reported; they coincide when nothing overlaps.
             tf = g["flops"] / (g["busy_ms"] * 1e-3) / 1e12
             tf_sum = g["flops"] / (g["ms"] * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_bt_kernel + gemm_pc_kernel (all epilogues)", "achieved": round(tf, 1),
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_bt_kernel + gemm_pc_kernel + gemm_pcp_kernel (all epilogues)", "achieved": round(tf, 1),
                                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
                                 "traffic": traffic, "launches_per_step": g["launches"] // n_sampled, "steps_sampled": n_sampled,
                                 "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),

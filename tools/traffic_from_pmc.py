@@ -13,14 +13,21 @@ def per_kernel(dbp, counter):
         a = agg.setdefault(re.sub(r"\(.*", "", k), [0, 0.0]); a[0] += 1; a[1] += float(v)
     return agg
 rd, wr = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-g = [k for k in rd if "gemm_bt_kernel" in k or "gemm_bt_phased_kernel" in k or "gemm_pc_kernel" in k]
+g = [k for k in rd if ("gemm_bt_kernel" in k or "gemm_bt_phased_kernel" in k or "gemm_pc_kernel" in k or "gemm_pcp_kernel" in k) and "sgemm" not in k]
 n = sum(rd[k][0] for k in g); fr = sum(rd[k][1] for k in g)
 nw = sum(wr[k][0] for k in g if k in wr); fw = sum(wr[k][1] for k in g if k in wr)
 what = sys.argv[3] if len(sys.argv) > 3 else "headline bench step"
-out = {"kernel": f"gemm_bt_kernel + gemm_bt_phased_kernel + gemm_pc_kernel (all epilogues/geometries, {what})", "launches_sampled": n,
+out = {"kernel": f"gemm_bt_kernel + gemm_bt_phased_kernel + gemm_pc_kernel + gemm_pcp_kernel (all epilogues/geometries, {what})", "launches_sampled": n,
        "FETCH_SIZE_kb_avg_raw": round(fr / n, 1), "WRITE_SIZE_kb_avg_raw": round(fw / nw, 1),
        "bytes_per_launch": int((2.0 * fr / n + fw / nw) * 1024),
        "correction": "2 x FETCH_SIZE (gfx950 half-count of 16 B/lane reads) + WRITE_SIZE; counters in KB; includes Infinity-Cache hits",
        "source": "two separate passes: rocprofv3 --pmc FETCH_SIZE --kernel-trace / rocprofv3 --pmc WRITE_SIZE --kernel-trace "
                  "-- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing"}
+# per instantiation (same correction), largest first: where the bytes of the average launch come from
+rows = []
+for k in g:
+    nk_, wk = rd[k][0], wr.get(k, [1, 0.0])
+    rows.append({"kernel": re.sub(r"^_ZN5mvlpt\d+", "", k)[:64], "launches": nk_, "MB_per_launch": round((2.0 * rd[k][1] / nk_ + wk[1] / max(wk[0], 1)) / 1024, 1),
+                 "fetch_MB_raw": round(rd[k][1] / nk_ / 1024, 1), "write_MB": round(wk[1] / max(wk[0], 1) / 1024, 1)})
+out["per_kernel"] = sorted(rows, key=lambda r: -r["MB_per_launch"] * r["launches"])
 print(json.dumps(out, indent=1))
