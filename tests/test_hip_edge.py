@@ -121,3 +121,21 @@ def test_trim_releases_outgrown_workspaces_and_the_engine_keeps_working():
     assert torch.equal(eng.image_fwd(small), f_small) and torch.equal(eng.image_fwd(big), f_big)
     eng.trim()                                                # nothing retired: a no-op
     assert torch.equal(eng.image_fwd(small), f_small)
+
+
+@pytest.mark.parametrize("arch_name,B", [("tiny", 5), ("ViT-B/32", 3), ("ViT-B/16", 2)])
+def test_image_dtypes_give_identical_features(arch_name, B):
+    """mvlpt_image_fwd takes fp32, fp16 or bf16 images (the 16-bit ones of the compute type go through the 16-byte patchify
+    fast path when the patch size allows): for pixel values both types hold exactly, the features are bit-identical."""
+    from mvlpt_amd.model import FrozenCLIP
+    from mvlpt_amd.weights import ARCHS, make_state_dict
+    arch = ARCHS[arch_name]
+    eng = FrozenCLIP(make_state_dict(arch, seed=3)).engine
+    g = torch.Generator().manual_seed(11)
+    x16 = torch.randn(B, 3, arch.image_resolution, arch.image_resolution, generator=g).half().cuda()
+    f32 = eng.image_fwd(x16.float()).clone()
+    f16 = eng.image_fwd(x16).clone()
+    assert torch.isfinite(f32).all() and float(f32.abs().max()) > 0
+    assert torch.equal(f16, f32), "fp16 and fp32 inputs holding the same pixel values must give the same features"
+    # non-contiguous views are made contiguous by the binding; a different batch offset must not matter
+    assert torch.equal(eng.image_fwd(x16[1:].contiguous()), f32[1:])
