@@ -993,6 +993,11 @@ __device__ __forceinline__ void stage_res8(char* buf, const T* src, size_t lo_of
 }
 }  // namespace
 
+// The K fragments of key tile kt + 1 are requested UNCONDITIONALLY in front of tile kt's MFMAs (tiles past the sequence still lie inside
+// the image): with the request inside `if (kt < nt)` hipcc's wait-count pass merges the "issued / not issued" paths pessimistically and
+// waits for the prefetched fragments in front of the current tile's MFMAs (lgkmcnt(3) .. (0) instead of (7) .. (4)): no overlap at all.
+// (A compile-time tile count makes the phases straight-line code, which hipcc schedules into 60-80 spilled registers — spill traffic
+// counts in vmcnt, its waits drain the prefetch DMA; leaving the tile loop with `break` turns S[][] into a dynamically indexed stack array.)
 template <typename T>
 __global__ __launch_bounds__(RNW * 64) void attn32p_fwd_kernel(Attn32Args a, int total) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -1035,28 +1040,46 @@ __global__ __launch_bounds__(RNW * 64) void attn32p_fwd_kernel(Attn32Args a, int
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // everybody's pieces of K_i, V_i are in; everybody is done with V_(i-1)
+    // the compiler's own vmcnt waits for the Q fragments (ordinary loads it tracks) must sit HERE, in front of the DMA it does not see:
+    // left to themselves they land inside the S phase (vmcnt(7) .. vmcnt(0) in front of every MFMA group) and drain the K_(i+1)
+    // requests just issued — the whole prefetch would be waited for on the spot
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) asm volatile("" ::"v"(Qh[o][ks]), "v"(Ql[o][ks]));
     if (next < total) stage_res8<T>(Nb, head_base(next) + d, lo, ld, L, wave, lane);          // K_(i+1)
-    // ---- S phase: both own tiles against every key tile
+    // ---- S phase: both own tiles against every key tile; the K fragments of tile kt + 1 are requested behind the first MFMA of tile
+    // kt (one fragment set in flight: a second buffer of 16 registers does not fit next to S[2][13] without spilling, and spill
+    // traffic counts in vmcnt: its waits would drain the prefetch DMA)
     f32x4 S[2][RNT];
+    v8 kf[4], kn[4];                           // ks * 2 + {hi, lo}: current / next tile
+    auto load_k = [&](int kt, v8 (&f)[4]) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) { f[ks * 2] = frag_rows<T>(Kb, kt, ks, fr, fg); f[ks * 2 + 1] = frag_rows<T>(Kb + RIMG, kt, ks, fr, fg); }
+    };
+    load_k(0, kf);
 #pragma unroll
     for (int kt = 0; kt < RNT; ++kt) {
       S[0][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; S[1][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < RNT) load_k(kt + 1, kn);    // UNCONDITIONAL (a compile-time test): inside the image whatever L is
+      __builtin_amdgcn_sched_barrier(0);
       if (kt < nt) {
         f32x4 acc[2][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const v8 ah = frag_rows<T>(Kb, kt, ks, fr, fg), al = frag_rows<T>(Kb + RIMG, kt, ks, fr, fg);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int o = 0; o < 2; ++o) {
-            if (o == 1 && !two) continue;
-            acc[o][ks] = mfma16<T>(ah, Qh[o][ks], f32x4{0.f, 0.f, 0.f, 0.f});
-            acc[o][ks] = mfma16<T>(ah, Ql[o][ks], acc[o][ks]);
-            acc[o][ks] = mfma16<T>(al, Qh[o][ks], acc[o][ks]);
+          for (int o = 0; o < 2; ++o) {        // (a wave without a second tile multiplies clamped rows: it would wait at the barrier otherwise)
+            acc[o][ks] = mfma16<T>(kf[ks * 2], Qh[o][ks], f32x4{0.f, 0.f, 0.f, 0.f});
+            acc[o][ks] = mfma16<T>(kf[ks * 2], Ql[o][ks], acc[o][ks]);
+            acc[o][ks] = mfma16<T>(kf[ks * 2 + 1], Qh[o][ks], acc[o][ks]);
           }
-        }
         S[0][kt] = acc[0][0] + acc[0][1];
-        if (two) S[1][kt] = acc[1][0] + acc[1][1];
+        S[1][kt] = acc[1][0] + acc[1][1];
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) kf[q] = kn[q];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();            // K_i is dead
@@ -1098,30 +1121,43 @@ __global__ __launch_bounds__(RNW * 64) void attn32p_fwd_kernel(Attn32Args a, int
     for (int o = 0; o < 2; ++o)
 #pragma unroll
       for (int i = 0; i < 4; ++i) O[o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (V^T fragments of the next column block requested unconditionally in front of this block's MFMAs, as in the S phase; a key
+    // block whose second tile lies past the sequence meets P = 0 there and finite, clamped rows in the image)
+    v8 vf[2], vn[2];
+    auto load_v = [&](int kb, int dt, v8 (&f)[2]) {
+      if (2 * kb + 1 >= RNT) { f[0] = frag_vt_half<T>(Vb, kb, dt, fr, fg); f[1] = frag_vt_half<T>(Vb + RIMG, kb, dt, fr, fg); }
+      else { f[0] = frag_vt<T>(Vb, kb, dt, fr, fg); f[1] = frag_vt<T>(Vb + RIMG, kb, dt, fr, fg); }
+    };
+    load_v(0, 0, vf);
 #pragma unroll
     for (int kb = 0; kb < (RNT + 1) / 2; ++kb) {
-      if (2 * kb >= nt) continue;
-      const bool half = 2 * kb + 1 >= nt;                 // the block's second tile does not exist (wave-uniform)
       v8 ph[2], pl[2];
+      if (2 * kb < nt) {
 #pragma unroll
-      for (int o = 0; o < 2; ++o)
+        for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          T x, y;
-          split16<T>(S[o][2 * kb][e], x, y); ph[o][e] = x; pl[o][e] = y;
-          split16<T>(2 * kb + 1 < RNT ? S[o][2 * kb + 1 < RNT ? 2 * kb + 1 : 0][e] : 0.f, x, y); ph[o][e + 4] = x; pl[o][e + 4] = y;
-        }
+          for (int e = 0; e < 4; ++e) {
+            T x, y;
+            split16<T>(S[o][2 * kb][e], x, y); ph[o][e] = x; pl[o][e] = y;
+            split16<T>(2 * kb + 1 < RNT ? S[o][2 * kb + 1 < RNT ? 2 * kb + 1 : 0][e] : 0.f, x, y); ph[o][e + 4] = x; pl[o][e + 4] = y;
+          }
+      }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const v8 vh = half ? frag_vt_half<T>(Vb, kb, dt, fr, fg) : frag_vt<T>(Vb, kb, dt, fr, fg);
-        const v8 vl = half ? frag_vt_half<T>(Vb + RIMG, kb, dt, fr, fg) : frag_vt<T>(Vb + RIMG, kb, dt, fr, fg);
+        __builtin_amdgcn_sched_barrier(0);
+        if (dt + 1 < 4) load_v(kb, dt + 1, vn);
+        else if (kb + 1 < (RNT + 1) / 2) load_v(kb + 1, 0, vn);
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 * kb < nt) {
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-          if (o == 1 && !two) continue;
-          O[o][dt] = mfma16<T>(vh, ph[o], O[o][dt]);
-          O[o][dt] = mfma16<T>(vh, pl[o], O[o][dt]);
-          O[o][dt] = mfma16<T>(vl, ph[o], O[o][dt]);
+          for (int o = 0; o < 2; ++o) {
+            O[o][dt] = mfma16<T>(vf[0], ph[o], O[o][dt]);
+            O[o][dt] = mfma16<T>(vf[0], pl[o], O[o][dt]);
+            O[o][dt] = mfma16<T>(vf[1], ph[o], O[o][dt]);
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        vf[0] = vn[0]; vf[1] = vn[1];
       }
     }
     // ---- outputs (8 stores per existing tile + lse)
