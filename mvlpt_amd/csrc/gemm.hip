@@ -1294,7 +1294,11 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   const int Keff = g.a_split == 2 ? g.K + g.K / 2 : (g.a_split ? 2 * g.K : g.K);
   // the round counts below are per compute unit the stream can use (a CU-partitioned stream: mvlpt_stream_create_cus)
   const long cus = stream_cus(s);
-  const bool big = g.N % 256 == 0 && (t256 >= 4 * cus || (t256 >= 2 * cus && Keff >= 2048));
+  // ... or when the 256x256 tiles fill exactly one round (0.75 .. 1 tile per CU: the text tower's N = 2048 GEMMs at M = 7 700 are
+  // 248 tiles): one tile time instead of two rounds of the 256x128 geometry
+  static const int one_round_on = getenv("MVLPT_GEMM_ONE_ROUND") ? atoi(getenv("MVLPT_GEMM_ONE_ROUND")) : 1;
+  const bool one_round = one_round_on && g.N % 256 == 0 && t256 <= cus && 4 * t256 >= 3 * cus;
+  const bool big = g.N % 256 == 0 && (t256 >= 4 * cus || (t256 >= 2 * cus && Keff >= 2048) || one_round);
   const bool r15 = 2 * t128 >= 3 * cus;      // >= 1.5 rounds of 256x128 tiles
   // (the phased kernel has no fp8 stages: mixed pairs take the plain 256x128 geometry)
   // (nor the LayerNorm-folding fields: folded GEMMs take the plain geometries)
