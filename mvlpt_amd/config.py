@@ -54,7 +54,7 @@ def get_cfg_default() -> CfgNode:
                    SGD_NESTEROV=False, LR_SCHEDULER="cosine", WARMUP_EPOCH=1, WARMUP_TYPE="constant",
                    WARMUP_CONS_LR=1e-5, WARMUP_MIN_LR=1e-5)
     cfg.TRAIN = CN(PRINT_FREQ=5, CHECKPOINT_FREQ=0)
-    cfg.TEST = CN(FINAL_MODEL="last_step", SPLIT="test", NO_TEST=True)   # NO_TEST: Dassl default False; True here because the synthetic data managers carry no test split unless a caller supplies one
+    cfg.TEST = CN(FINAL_MODEL="last_step", SPLIT="test", NO_TEST=False)   # Dassl's defaults; a run without evaluation data sets NO_TEST True
     cfg.TRAINER = CN(NAME="MVLPT", CUT_CONTEXTLEN=False, ACT_CKPT=1)
     cfg.TRAINER.MVLPT = CN(
         PREC="fp16", PROJECT_METHOD="transformer", PROJECT_DIM=128,

@@ -538,14 +538,19 @@ int prepare_fold(Engine* E, hipStream_t s) {
       for (int k = 0; k < 2; ++k) {
         Linear& L = k ? B.fc : B.qkv;
         const LNp& ln = k ? B.ln2 : B.ln1;
-        void* p = nullptr;
-        HIPCHK(E, hipMalloc(&p, (size_t)L.out * 2 * sizeof(float)));
-        E->owned.push_back(p);
-        L.fold_s = (float*)p; L.fold_b = (float*)p + L.out;
+        if (!L.fold_s) {      // (kept across reloads of the frozen tensors: the shapes are fixed by the architecture)
+          void* p = nullptr;
+          HIPCHK(E, hipMalloc(&p, (size_t)L.out * 2 * sizeof(float)));
+          E->owned.push_back(p);
+          L.fold_s = (float*)p; L.fold_b = (float*)p + L.out;
+        }
         HIPCHK(E, launch_fold_vectors(E->dt, L.w, L.ldw, ln.g, ln.b, L.b, L.fold_s, L.fold_b, L.out, d, s));
       }
     }
   }
+  // Both towers' vectors are computed on the stream of whichever tower gets here first; the other tower runs on another
+  // stream and reads them without any dependency on `s`.  One host-side wait, once per (re)load of the frozen tensors.
+  HIPCHK(E, hipStreamSynchronize(s));
   E->fold_ready = true;
   return 0;
 }
@@ -664,6 +669,7 @@ int mvlpt_load_frozen(void* h, const char* name, const void* dev_ptr, int dtype,
   for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
   std::string nm(name);
   if (nm == "logit_scale" || nm == "token_embedding.weight") return 0;  // not used by the towers
+  E->fold_ready = false;      // W gamma / b + W beta of the LayerNorm folding are rebuilt from the new tensors (prepare_fold)
   // stage as fp32
   const float* p32 = (const float*)dev_ptr;
   if (dtype != MVLPT_DT_F32) {

@@ -562,7 +562,8 @@ class CustomCLIP(nn.Module):
         self._eval_text_cache = None
         self.trim_text_to_eot = False
         self._prefetch_stream = None
-        self._prefetched = {}                     # (data_ptr, shape, version) of an image tensor -> (features, event)
+        self._prefetched = {}                     # (data_ptr, shape, version) of an image tensor -> (features, event, the tensor:
+                                                  # holding it pins its storage, so the pointer cannot be handed to another batch)
         self._fwd_generation = 0
         self._side_stream = torch.cuda.Stream(device=clip_model.device) if torch.cuda.is_available() else None
         self._text_partition = None
@@ -643,15 +644,15 @@ class CustomCLIP(nn.Module):
         image.record_stream(st)
         if len(self._prefetched) >= 4:            # never picked up (a loop that reads ahead without consuming): keep the newest
             self._prefetched.pop(next(iter(self._prefetched)))
-        self._prefetched[key] = (feat, ev)
+        self._prefetched[key] = (feat, ev, image)
         return True
 
     def drop_prefetch(self) -> None:
         """Forget prefetched image forwards that nobody will pick up (the loop left the loader early): the main stream
         waits for the side stream so that the image-tower workspace is quiescent for whatever runs next."""
         pre, self._prefetched = self._prefetched, {}
-        for feat, ev in pre.values():
-            torch.cuda.current_stream().wait_event(ev)
+        for entry in pre.values():
+            torch.cuda.current_stream().wait_event(entry[1])
 
     def forward(self, image, task=None):
         coop_emb, vpt_emb, vpt_emb_deep = self.prompt_learner.forward_mvlpt_proj(self.dtype)

@@ -258,6 +258,9 @@ class TrainerX:
                 self.save_model(self.epoch, self.output_dir, val_result=curr, model_name="model-best.pth.tar")
         if last_epoch or (freq > 0 and (self.epoch + 1) % freq == 0):
             self.save_model(self.epoch, self.output_dir)
+        # rank 0 writes the checkpoints; nobody goes on (to after_train's load_model of model-best.pth.tar in particular)
+        # before the files are complete
+        dist_utils.barrier()
 
     def after_train(self):
         """Dassl's after_train: final test, on the best-validation checkpoint when that is the model selection rule."""
@@ -511,6 +514,9 @@ class MVLPT(TrainerX):
         self.set_model_mode("eval")
         split = split or self.cfg.TEST.SPLIT
         loader = self.val_loader if (split == "val" and self.val_loader is not None) else self.test_loader
+        if loader is None:
+            raise RuntimeError(f"test(split={split!r}): the data manager has no val/test loader; set TEST.NO_TEST True for "
+                               "runs without evaluation data")
         coop = self.cfg.DATASET.COOP
         correct = torch.zeros((), device=self.device)
         total = 0

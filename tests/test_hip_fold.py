@@ -162,3 +162,31 @@ def test_full_size_fixtures_with_folding_forced_on(arch_name, name):
         _check_inference(case, _inference_logits(case, build_model(case, clip, res, pre, suf), image), name)
     finally:
         clip.engine.set_ln_fold(2, 4096)
+
+
+@pytest.mark.parametrize("mean_over_std,outlier,tol", [(10.0, 300.0, 3e-3), (100.0, 2000.0, 1.2e-2)])
+def test_fold_rows_with_large_mean_and_outlier_channels(mean_over_std, outlier, tol):
+    """the folded path keeps round16(x * gamma) UN-normalised in fp16 and rebuilds the variance as E[x^2] - mean^2 from
+    fp32 partial sums.  Rows whose mean dwarfs their spread and channels hundreds of times the typical magnitude (the 'massive
+    activations' of real ViT checkpoints) are where that loses digits: the first case (mean = 10 std, a channel at 300) must stay
+    inside the ordinary bound; the second (mean = 100 std, a channel at 2 000: fp32 cancellation costs ~1e-7 * mean^2 / var ~ 1e-3 of
+    the variance) documents how far the formulation degrades, and that nothing overflows (|x * gamma| stays far below 65 504)."""
+    E = _E()
+    L = E._lib
+    dtype, dev = torch.float16, "cuda"
+    M, N1, K1, N2 = 4096, 768, 768, 2304
+    A, W1, b1, resid, gamma, beta, W2, b2 = _problem(M, N1, K1, N2, 11, dtype)
+    g = torch.Generator().manual_seed(12)
+    resid = torch.randn(M, N1, generator=g) + mean_over_std * (1.0 + 0.5 * torch.rand(M, 1, generator=g))
+    resid[:, 5] = outlier * (1.0 + 0.1 * torch.randn(M, generator=g))
+    A16 = A.to(dtype)
+    out32, x16, part, nt = E.op_gemm_ln_producer(A16.to(dev), W1.to(dtype).to(dev), b1.to(dev), resid.to(dev), gamma.to(dev))
+    assert bool(torch.isfinite(x16.float()).all())
+    cs, bias2 = E.op_fold_vectors(W2.to(dtype).to(dev), N1, gamma.to(dev), beta.to(dev), b2.to(dev))
+    res = E.op_gemm_folded(x16, W2.to(dtype).to(dev), cs, bias2, part, nt, epi=L.EPI_STORE16)
+    y = torch.nn.functional.layer_norm(out32.double().cpu(), (N1,), gamma.double(), beta.double(), 1e-5) @ W2.double().t() + b2.double()
+    h16 = E.op_layernorm_fwd(out32, gamma.to(dev), beta.to(dev), dtype)
+    plain = E.op_gemm(h16, W2.to(dtype).to(dev), L.EPI_STORE16, bias=b2.to(dev))
+    e_fold, e_plain = relerr(res, y), relerr(plain, y)
+    print(f"mean/std {mean_over_std:g}, outlier {outlier:g}: folded {e_fold:.2e}, stand-alone LayerNorm {e_plain:.2e}")
+    assert e_fold < tol

@@ -149,3 +149,59 @@ def test_best_val_checkpoint_flow(tmp_path):
     # after_train loaded the best checkpoint (epoch 2's parameters, not the last epoch's) before the final test
     for n, p in tr.model.prompt_learner.named_parameters():
         assert torch.equal(p.detach(), after[1][2][n]), n
+
+
+def _best_val_rank(rank, world, port, out_dir, ret):
+    """One rank of the two-rank best-val flow: the LAST epoch is the best one and rank 0's torch.save is slow, so a rank that
+    ran ahead of the checkpoint (no barrier behind save_model) would open a missing or truncated model-best.pth.tar."""
+    import time
+
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from mvlpt_amd import distributed as D
+    from tests.train_step_util import EpochLoader
+    D.init_process_group("gloo")
+    z = load_npz("tiny_train_steps")
+    tr = _oracle_trainer(z)
+    tr.rank, tr.world_size = rank, world
+    tr.cfg.TEST.FINAL_MODEL, tr.cfg.TEST.NO_TEST, tr.cfg.DATASET.COOP = "best_val", False, True
+    tr.output_dir, tr.start_epoch, tr.dm = out_dir, 0, None
+    batches = [{"img": t(z["images"][i]), "label": t(z["labels"][i]), "domain": torch.zeros(4, dtype=torch.long)} for i in range(3)]
+    tr.train_loader_x = EpochLoader(batches)
+    tr.val_loader, tr.test_loader = batches[:2], batches[2:]
+    seen = []
+    real_test, real_save = tr.test, tr.save_model
+
+    def scripted_test(split=None):
+        acc = real_test(split)
+        if split == "val":
+            seen.append([30.0, 40.0, 50.0][len(seen)])
+            return seen[-1]
+        return acc
+
+    def slow_save(epoch, directory, **kw):
+        if rank == 0:
+            time.sleep(0.5)
+        return real_save(epoch, directory, **kw)
+
+    tr.test, tr.save_model = scripted_test, slow_save
+    tr.train()
+    mine = torch.cat([p.detach().flatten() for p in tr.model.prompt_learner.parameters()])
+    best = torch.load(os.path.join(out_dir, "prompt_learner", "model-best.pth.tar"), map_location="cpu")
+    want = torch.cat([best["state_dict"][n].flatten() for n, _ in tr.model.prompt_learner.named_parameters()])
+    ret[rank] = bool(best["epoch"] == 3 and torch.equal(mine, want))
+    dist.destroy_process_group()
+
+
+def test_best_val_checkpoint_flow_two_ranks(tmp_path):
+    """every rank loads the best checkpoint only after rank 0 has finished writing it."""
+    import socket
+
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_best_val_rank, args=(2, port, str(tmp_path), ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
