@@ -3,7 +3,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := mvlpt_amd/csrc
 OBJDIR := build/obj
-SRCS  := $(CSRC)/gemm.hip $(CSRC)/norm.hip $(CSRC)/attention.hip $(CSRC)/attention_stream.hip $(CSRC)/attention32.hip $(CSRC)/glue.hip $(CSRC)/preprocess.hip $(CSRC)/engine.hip
+SRCS  := $(CSRC)/gemm.hip $(CSRC)/gemm_duo.hip $(CSRC)/norm.hip $(CSRC)/attention.hip $(CSRC)/attention_stream.hip $(CSRC)/attention32.hip $(CSRC)/glue.hip $(CSRC)/preprocess.hip $(CSRC)/engine.hip
 OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result -Wno-inline-asm
 LIB   := mvlpt_amd/libmvlpt_hip.so
@@ -17,7 +17,7 @@ $(ORACLE_SO): oracle/resample_oracle.c
 	@mkdir -p oracle/_build
 	gcc -O2 -ffp-contract=off -shared -fPIC -o $@ $< -lm
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/attn_common.h include/mvlpt_hip.h
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/attn_common.h $(CSRC)/gemm_epi.h include/mvlpt_hip.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 

@@ -178,6 +178,46 @@ class _CyclingLoader:
             yield self.batches[i % len(self.batches)]
 
 
+# BASELINE.json configs[2..4] at their per-GPU shapes on ONE GPU: short fenced passes run AFTER (and outside) the headline's timed
+# region, each in its own process of this same script, so that the driver's line carries an observation of every BASELINE
+# configuration and not only of configs[1].  cfg4 is listed with CUT_CONTEXTLEN (the reference's multitask
+# scripts set TRAINER.CUT_CONTEXTLEN True) — its L = 77 variant is the `tools/config_sweep.sh` line.
+SECONDARY_CONFIGS = [
+    ("BASELINE configs[2]: MVLPT VPT-deep (8 visual prompt tokens / layer), ViT-B/16, ImageNet-1k class list, per-GPU batch 256",
+     ["--method", "vpt", "--classes", "1000", "--batch", "256", "--steps", "6", "--warmup", "2"]),
+    ("BASELINE configs[3]: MVLPT UPT (4 text + 4 visual prompts, joint projection), ViT-B/16, 11-dataset class list (2191), per-GPU batch 256, CUT_CONTEXTLEN",
+     ["--method", "upt", "--classes", "2191", "--batch", "256", "--cut", "--steps", "4", "--warmup", "2"]),
+    ("BASELINE configs[4]: MVLPT UPT, ViT-L/14@336px, ELEVATER-20 class list (1151), per-GPU batch 128",
+     ["--arch", "ViT-L/14@336px", "--method", "upt", "--classes", "1151", "--batch", "128", "--steps", "3", "--warmup", "1"]),
+]
+
+
+def run_secondary_configs(dtype):
+    import subprocess
+    out = []
+    t_all = time.perf_counter()
+    for workload, flags in SECONDARY_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--dtype", dtype, "--no-cpu-baseline", "--no-kernel-timing",
+               "--no-trim-extra", "--no-secondary"] + flags
+        t0 = time.perf_counter()
+        entry = {"workload": workload, "flags": " ".join(flags)}
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or len(lines) != 1:
+                entry["error"] = (r.stderr or r.stdout)[-400:]
+            else:
+                j = json.loads(lines[0])
+                entry.update({"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "warmup": j["warmup"],
+                              "step_mfma_fraction": j["step_mfma_fraction"], "algorithmic_gflop_per_image": j["algorithmic_gflop_per_image"],
+                              "per_gpu_batch": j["config"]["per_gpu_batch"], "child_workload": j["config"]["workload"]})
+        except subprocess.TimeoutExpired:
+            entry["error"] = "timed out after 240 s"
+        entry["wall_s"] = round(time.perf_counter() - t0, 1)
+        out.append(entry)
+    return out, round(time.perf_counter() - t_all, 1)
+
+
 def _respawn_under_torchrun(n):
     """`python bench.py --gpus N` without a launcher: start N ranks ourselves (one process per GPU, RCCL), as the
     reference gets its replicas from one process (nn.DataParallel, trainers/mvlpt.py:877-880)."""
@@ -220,6 +260,7 @@ def main():
                     help="compute units of the text tower's partition when the two towers run side by side (CustomCLIP.set_cu_partition; "
                          "0 = shared streams); default: the library's (MVLPT_TEXT_CUS / model.DEFAULT_TEXT_CUS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short passes of BASELINE configs[2..4] behind the headline run")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--all-kernel-timing", action="store_true", help="bracket every kernel class with marker events (slower)")
     args = ap.parse_args()
@@ -475,6 +516,11 @@ def main():
                 a32 = _A["ViT-B/32"]
                 line["cpu_baseline_cfg1"] = cpu_baseline_images_per_sec(a32, _mk(a32, seed=cfg.SEED), args.classes, L_text, n_ctx, pre, B_cpu=32)
                 line["cpu_baseline_cfg1"]["config"] = "BASELINE configs[0]: CoOp ViT-B/32, 100 classes, n_ctx=16, L=77, full batch of 32"
+        if is_headline and world == 1 and not args.no_secondary and args.grad_precision == "split_grad":
+            # this process is done with the GPU (everything above is synchronised): the children have it to themselves
+            del trainer, dm
+            torch.cuda.empty_cache()
+            line["secondary_configs"], line["secondary_configs_wall_s"] = run_secondary_configs(args.dtype)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

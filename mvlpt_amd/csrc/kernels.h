@@ -92,6 +92,11 @@ int gemm_tile_n(int dtype, int epi, const GemmArgs& g, hipStream_t s);
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hipEvent_t ev_start = nullptr,
                        hipEvent_t ev_stop = nullptr);
 
+// gemm_duo.hip: two half-tile wave groups per workgroup, the epilogue of one under the matrix work of the other (launch_gemm
+// routes the problems `gemm_duo_takes` accepts there)
+bool gemm_duo_takes(int epi, const GemmArgs& g, hipStream_t s);
+hipError_t launch_gemm_duo(int dtype, int epi, const GemmArgs& g, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop);
+
 // fp32 GEMM on the f32-input MFMA (exact f32 products, v_mfma_f32_16x16x4_f32) for the two tiny projections
 // next to the logits (CLS / EOT rows only): C[M,N] = alpha * A[M,K] * Bt[N,K]^T.  K % 16 == 0, N % 4 == 0.
 hipError_t launch_sgemm_bt(const float* A, const float* Bt, float* C, int M, int N, int K, const float* alpha_dev, hipStream_t s);

@@ -38,6 +38,16 @@ def test_bench_line_contract():
     assert j["text_trimmed_to_eot"]["text_positions_evaluated"] < 77 and j["text_trimmed_to_eot"]["value"] > j["value"] * 0.9
     if "clock" in j:
         assert 100.0 < j["clock"]["sclk_mhz_avg"] <= 2500.0 and j["clock"]["samples"] >= 2
+    # BASELINE configs[2..4]: short fenced passes behind (and outside) the headline's timed region, in the same line
+    sec = j["secondary_configs"]
+    assert len(sec) == 3 and [e["workload"].split(":")[0] for e in sec] == [f"BASELINE configs[{i}]" for i in (2, 3, 4)]
+    for e in sec:
+        assert "error" not in e, e
+        for k in ("workload", "value", "ms_per_step", "step_mfma_fraction", "steps"):
+            assert k in e, k
+        assert e["value"] > 0 and abs(e["value"] - e["per_gpu_batch"] * 1e3 / e["ms_per_step"]) / e["value"] < 1e-3
+        assert 0.02 < e["step_mfma_fraction"] < 1.0
+    assert j["secondary_configs_wall_s"] < 150
 
 
 @pytest.mark.gpu
