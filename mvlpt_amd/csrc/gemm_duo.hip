@@ -27,6 +27,17 @@
 
 namespace mvlpt {
 
+// Debug timeline (tools/duo_trace.py): -DMVLPT_GEMM_TRACE builds record (point << 56 | s_memtime) per wave of workgroup 0.
+// Points: 1 / 2 / 3 = behind the closing barrier of a stage the wave spent multiplying / in its epilogue / idle; 4 = in front of the
+// stage's vmcnt wait.
+#ifdef MVLPT_GEMM_TRACE
+constexpr int DUO_TR_MAX = 2048;
+#define DUO_TR(p) do { if (g.trace && blockIdx.x == 0 && lane == 0 && tr_n < DUO_TR_MAX) \
+    g.trace[wave * DUO_TR_MAX + tr_n++] = ((long long)(p) << 56) | ((long long)__builtin_amdgcn_s_memtime() & 0xffffffffffffffLL); } while (0)
+#else
+#define DUO_TR(p) do { } while (0)
+#endif
+
 // async global -> LDS copy, 16 B per lane, from inline asm (M0 = wave-uniform LDS byte address, saved and restored: the register
 // belongs to the compiler).  Not counted by hipcc: every wait for it is an explicit s_waitcnt below.
 __device__ __forceinline__ void glds16_raw(const void* gsrc, unsigned lds_addr) {
@@ -43,7 +54,7 @@ constexpr int DUO_BIAS_OFF = DUO_SCR_OFF + 4 * EPI_SCRATCH_PER_WAVE;     // the 
 constexpr int DUO_LDS = DUO_BIAS_OFF + 1024;
 
 template <typename T, int EPI, int E>
-__global__ __launch_bounds__(512, 2) void gemm_duo_kernel(GemmArgs g, int J) {
+__global__ __launch_bounds__(512, 2) void gemm_duo_kernel(GemmArgs g, int J, int d_req) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using v8 = typename Vec<T>::v8;
   static_assert(E == 2 || E == 4, "epilogue stages per half tile");
@@ -56,6 +67,9 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(GemmArgs g, int J) {
   const int ldb = g.ldb ? g.ldb : K;
   const T* __restrict__ A = (const T*)g.A;
   const T* __restrict__ Bt = (const T*)g.Bt;
+#ifdef MVLPT_GEMM_TRACE
+  int tr_n = 0;
+#endif
 
   // workgroup -> (row chunk j, weight panel n): panels fastest, so the workgroups an XCD runs side by side walk the same rows of A
   const int tilesN = N / 256;
@@ -68,7 +82,7 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(GemmArgs g, int J) {
   const int c0 = (cnt + 1) >> 1, c1 = cnt >> 1;        // half tiles of group 0 / group 1 (alternating: h0 + 2t + grp)
   const int c_me = grp ? c1 : c0;
   const int nk = K / BK, P = nk + E;
-  int d = P >> 1;                                      // group 1 starts d stages behind: E <= d <= nk keeps the two epilogues apart
+  int d = d_req > 0 ? d_req : (P >> 1);                // group 1 starts d stages behind: E <= d <= nk keeps the two epilogues apart
   d = d < E ? E : (d > nk ? nk : d);
   const int S = c1 ? (c0 * P > d + c1 * P ? c0 * P : d + c1 * P) : c0 * P;
 
@@ -124,15 +138,16 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(GemmArgs g, int J) {
   };
 
   int s = 0;
-  auto end_stage = [&]() {
+  auto end_stage = [&](int role) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    DUO_TR(role);
     ++s;
   };
   auto idle_stage = [&]() {
     request_next();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    end_stage();
+    end_stage(3);
   };
 
   // ---- fragment addressing (the wave's 128 x 64 block of its group's half tile)
@@ -201,15 +216,16 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(GemmArgs g, int J) {
         __builtin_amdgcn_sched_barrier(0);
         if (sg == 2 && grp) request_next();
       }
+      DUO_TR(4);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      end_stage();
+      end_stage(1);
     }
 
     // ---- epilogue stages: chunk c of E; the SIMD partners (other group) multiply meanwhile
     const int r0 = (h0 + 2 * t + grp) * 128;
     const int nbase = n * 256 + w4 * 64;
     FoldCtx fc{nullptr, nullptr, 0, w4, 4, 0};
-    fc.bias_lds = smem + DUO_BIAS_OFF;
+    fc.bias_lds = (const __attribute__((address_space(3))) char*)(smem + DUO_BIAS_OFF);
     constexpr int NOUT_MAX = (epi_base(EPI) == EPI_GELU) ? 2 : 1;
 #pragma unroll
     for (int c = 0; c < E; ++c) {
@@ -226,11 +242,12 @@ __global__ __launch_bounds__(512, 2) void gemm_duo_kernel(GemmArgs g, int J) {
       // the request above is older than this chunk's stores: with all of them issued (no row beyond M) it has landed once at
       // most that many operations are outstanding
       const bool two = NOUT_MAX == 2 && g.out2 != nullptr;
+      DUO_TR(4);
       if (rows_end <= M) {
         if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 4 * HPC) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * HPC) : "memory");
       } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      end_stage();
+      end_stage(2);
     }
   }
   while (s < S) idle_stage();
@@ -248,7 +265,8 @@ static hipError_t launch_duo_e(const GemmArgs& g, hipStream_t s, hipEvent_t ea, 
   int J = cus / tilesN;
   if (J > MH) J = MH;
   if (J < 1) return hipErrorInvalidValue;
-  hipExtLaunchKernelGGL((gemm_duo_kernel<T, EPI, E>), dim3(J * tilesN), dim3(512), DUO_LDS, s, ea, eb, 0, g, J);
+  static const int d_req = getenv("MVLPT_DUO_D") ? atoi(getenv("MVLPT_DUO_D")) : 0;      // experiment: stagger of the groups in stages (0: half a tile life)
+  hipExtLaunchKernelGGL((gemm_duo_kernel<T, EPI, E>), dim3(J * tilesN), dim3(512), DUO_LDS, s, ea, eb, 0, g, J, d_req);
   return hipGetLastError();
 }
 

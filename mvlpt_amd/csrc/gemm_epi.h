@@ -49,7 +49,9 @@ struct FoldCtx {
   int mrel;      // first row of this wave's 64x64 block inside the tile
   int wn, wcn;   // column block of the wave / number of column blocks (producer)
   int xs;        // producer: format of the 16-bit copy (GemmArgs::ln_split; a compile-time 2 in the mixed-pair kernels)
-  const char* bias_lds = nullptr;   // gemm_duo.hip: the bias of the workgroup's column panel in LDS (wn * 64 + column), instead of g.bias
+  // gemm_duo.hip: the bias of the workgroup's column panel in LDS (wn * 64 + column) instead of g.bias.  Typed as an LDS pointer:
+  // through a generic one hipcc emits flat loads, whose waits (vmcnt(0) lgkmcnt(0)) would drain the LDS-DMA queue
+  const __attribute__((address_space(3))) char* bias_lds = nullptr;
 };
 // {rstd, -rstd * mean} of tile row `row_rel`: the table fold_build_coef left behind the partials
 __device__ __forceinline__ void fold_row_coef(const GemmArgs&, const char* tab, int row_rel, float& a, float& cc) {
@@ -122,7 +124,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
   for (int j = 0; j < 4; ++j) bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (fc.bias_lds && EPI != EPI_RESID32_LN && !fold) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(fc.bias_lds + (fc.wn * 64 + j * 16 + fg * 4) * 4);
+    for (int j = 0; j < 4; ++j) bv[j] = *(const __attribute__((address_space(3))) f32x4*)(fc.bias_lds + (fc.wn * 64 + j * 16 + fg * 4) * 4);
   } else if (g.bias && EPI != EPI_RESID32_LN && !fold) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + nbase + j * 16 + fg * 4);
@@ -174,12 +176,24 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // All four row-segment reads of the pass in flight at once, then the stores.  (One read -> wait -> guarded store at a time
+        // was four serialised LDS round trips plus four exec-mask branches per pass: ~1 700 cycles per 32 rows, the bulk of the
+        // 16-bit epilogue's time — tools/duo_trace.py.)  Whole passes inside the matrix (every tile but the last row of tiles)
+        // store without per-lane guards.
+        {
+          const int c = lane & 7, r0 = lane >> 3;             // 8 lanes x 16 B = one 128-B row segment
+          v8 w[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int r = it * 8 + (lane >> 3), c = lane & 7;   // 8 lanes x 16 B = one 128-B row segment
-          const v8 w = *(const v8*)(rows16(r) + c * 16);
-          const int m = mbase + half * 32 + r;
-          if (m < M) __builtin_nontemporal_store(w, (v8*)(outp + (size_t)m * N + nbase + c * 8));
+          for (int it = 0; it < 4; ++it) w[it] = *(const v8*)(rows16(it * 8 + r0) + c * 16);
+          T* const o0 = outp + (size_t)(mbase + half * 32 + r0) * N + nbase + c * 8;
+          if (mbase + half * 32 + 32 <= M) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) __builtin_nontemporal_store(w[it], (v8*)(o0 + (size_t)it * 8 * N));
+          } else {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+              if (mbase + half * 32 + it * 8 + r0 < M) __builtin_nontemporal_store(w[it], (v8*)(o0 + (size_t)it * 8 * N));
+          }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // scratch is rewritten by the next pass
       }
