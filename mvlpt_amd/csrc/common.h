@@ -123,9 +123,22 @@ __device__ __forceinline__ float quick_gelu_grad(float u) {
 }
 
 // async global -> LDS copy, 16 B per lane; LDS destination = wave-uniform base + lane*16
+#ifndef MVLPT_GLDS_ASM
+#define MVLPT_GLDS_ASM 0
+#endif
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+#if MVLPT_GLDS_ASM
+  // from inline asm (M0 saved and restored: it belongs to the compiler): hipcc neither counts the request in vmcnt nor orders
+  // it against its own LDS accesses — every wait for it is an explicit s_waitcnt at the call sites
+  // (the low 32 bits of a generic pointer into the LDS aperture are the LDS byte address)
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+#else
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
 }
 
 // same with the non-temporal (streaming) cache policy: for operands that exactly one workgroup reads once

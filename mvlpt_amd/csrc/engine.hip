@@ -1123,6 +1123,9 @@ int mvlpt_op_gemm(int dtype, int epi, const void* A, const void* Bt, int M, int 
                   const float* resid, void* out, void* out2, mvlpt_stream_t stream) {
   GemmArgs g{A, Bt, M, N, K, bias, aux, resid, out, out2};
 #ifdef MVLPT_GEMM_TRACE
+  // debug builds: row pitches of A / Bt from the environment (tools/pitch_probe.py allocates the operands that wide)
+  if (getenv("MVLPT_DBG_LDA")) g.lda = atoi(getenv("MVLPT_DBG_LDA"));
+  if (getenv("MVLPT_DBG_LDB")) g.ldb = atoi(getenv("MVLPT_DBG_LDB"));
   // debug builds: timeline of workgroup 0 -> $MVLPT_GEMM_TRACE_FILE (8 waves x 2048 int64 records)
   const char* path = getenv("MVLPT_GEMM_TRACE_FILE");
   long long* tr = nullptr;

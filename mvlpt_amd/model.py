@@ -565,7 +565,9 @@ class CustomCLIP(nn.Module):
         self._prefetched = {}                     # (data_ptr, shape, version) of an image tensor -> (features, event, the tensor:
                                                   # holding it pins its storage, so the pointer cannot be handed to another batch)
         self._fwd_generation = 0
-        self._side_stream = torch.cuda.Stream(device=clip_model.device) if torch.cuda.is_available() else None
+        # MVLPT_TEXT_PRIORITY=1 (experiment): the text tower's stream above, the image prefetch stream below the default priority
+        self._prio = os.environ.get("MVLPT_TEXT_PRIORITY", "0") != "0"
+        self._side_stream = torch.cuda.Stream(device=clip_model.device, priority=-1 if self._prio else 0) if torch.cuda.is_available() else None
         self._text_partition = None
         self.text_cus = 0
         if self._side_stream is not None:
@@ -630,7 +632,7 @@ class CustomCLIP(nn.Module):
             return True
         main = torch.cuda.current_stream()
         if self._prefetch_stream is None:
-            self._prefetch_stream = torch.cuda.Stream(device=self.clip_model.device)
+            self._prefetch_stream = torch.cuda.Stream(device=self.clip_model.device, priority=1 if self._prio else 0)
         st = self._prefetch_stream
         # the image tensor was produced (uploaded) on the main stream; an image forward that ran on the main stream itself
         # (no prefetch: the first step, an evaluation) must be done with the tower workspace
