@@ -62,6 +62,12 @@ int mvlpt_set_precision(void* handle, int mode);
  * stand-alone LayerNorm pass over the residual stream disappears.  mode 0: off, 1: image tower, 2: both towers (default;
  * environment MVLPT_LN_FOLD); towers with fewer than `min_rows` token rows (default 4096) keep the stand-alone kernel. */
 int mvlpt_set_ln_fold(void* handle, int mode, int min_rows);
+/* `vpt_dropout` of the reference (trainers/mvlpt.py:165, 424 and :77): the visual prompt rows are expanded over the batch and THEN
+ * dropped out, so every image has its own mask.  masks = fp32 [n_layers, B, n_vpt, width] on the device, 0 or 1 / (1 - p): layer 0
+ * belongs to the shallow prompts, layer l >= 1 to the deep prompts spliced in front of block l.  The NEXT mvlpt_image_fwd multiplies
+ * the prompt rows it writes with them and mvlpt_image_bwd the gradients it sums over the batch; the caller keeps the buffer alive
+ * until that backward and clears the setting with masks = NULL (evaluation, TRAINER.MVLPT.VPT.DROPOUT = 0). */
+int mvlpt_set_vpt_dropout(void* handle, const float* masks, int n_layers);
 /* Workspaces only grow, and a block that was outgrown is retired (not freed) so that no step ever meets a device-wide sync.
  * mvlpt_trim synchronises the device and releases the retired blocks: call it at an epoch boundary (e.g. after a one-off large
  * evaluation batch or class list). */

@@ -147,6 +147,8 @@ struct Engine {
   int fold_mode = 2;    // LayerNorm folding: 0 off, 1 image tower, 2 both towers (MVLPT_LN_FOLD, mvlpt_set_ln_fold)
   int fold_min_rows = 4096;   // towers with fewer token rows keep the stand-alone LayerNorm (a handful of tiles: nothing to win)
   bool fold_ready = false;
+  const float* vpt_mask = nullptr;   // mvlpt_set_vpt_dropout: [layers, B, n_vpt, d] masks of the visual prompt rows, or null
+  int vpt_mask_layers = 0;
   bool lo8 = true;      // split towers of MVLPT_PREC_SPLIT_GRAD use the mixed pair (hi + e5m2 residual byte; MVLPT_SPLIT_LO8=0: 16-bit pairs)
   std::string err;
   TowerW vis, txt;
@@ -642,6 +644,14 @@ int mvlpt_set_ln_fold(void* h, int mode, int min_rows) {
   return 0;
 }
 
+int mvlpt_set_vpt_dropout(void* h, const float* masks, int n_layers) {
+  Engine* E = (Engine*)h;
+  if (!E || (masks && n_layers <= 0)) return fail(E, MVLPT_ERR_ARG, "set_vpt_dropout: invalid argument");
+  E->vpt_mask = masks;
+  E->vpt_mask_layers = masks ? n_layers : 0;
+  return 0;
+}
+
 int mvlpt_trim(void* h) {
   Engine* E = (Engine*)h;
   if (!E) return MVLPT_ERR_ARG;
@@ -779,11 +789,14 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   st.fold = E->fold_mode >= 1 && (size_t)B * Lv >= (size_t)E->fold_min_rows && dv >= 256;
   if (st.fold) if (int rc = prepare_fold(E, s)) return rc;
 
+  // vpt_dropout masks of layer l's prompt rows (mvlpt_set_vpt_dropout), or null
+  if (E->vpt_mask && (n_vpt <= 0 || E->vpt_mask_layers < 1 + n_deep)) return fail(E, MVLPT_ERR_ARG, "image_fwd: the prompt dropout masks do not cover every prompted layer");
+  auto vmask = [&](int l) -> const float* { return E->vpt_mask ? E->vpt_mask + (size_t)l * B * n_vpt * dv : nullptr; };
   { ProfScope ps(E, s, PC_GLUE, 0, (double)npatch * E->Kp * 6.0);
     HIPCHK(E, launch_patchify(E->dt, image, image_dtype, patches, B, A.image_resolution, A.patch_size, E->Kp, s)); }
   HIPCHK(E, gemm(E, EPI_STORE32, patches, WRef{E->conv_w, 0, 0}, (int)npatch, dv, E->Kp, nullptr, nullptr, nullptr, pe, nullptr, s));
   { ProfScope ps(E, s, PC_GLUE, 0, (double)B * Lv * dv * 8.0);
-    HIPCHK(E, launch_assemble_tokens(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, vpt, n_vpt, st.x[0], B, G2, dv, s)); }
+    HIPCHK(E, launch_assemble_tokens(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, vpt, n_vpt, st.x[0], B, G2, dv, s, vmask(0))); }
   bool cls_only_last = false;
   bool ln1_ready = false;       // LayerNorm folding: the previous block's FC2 left this block's ln_1 input in folded form
   // ln_1 of block l can be folded when nothing touches the residual stream between FC2 of block l-1 and it: not behind a
@@ -798,7 +811,7 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
     if (l > 0 && n_deep > 0) {
       if (l <= n_deep) {
         ProfScope ps(E, s, PC_GLUE, 0, (double)B * n_vpt * dv * 4.0);
-        HIPCHK(E, launch_overwrite_rows(vpt_deep + (size_t)(l - 1) * n_vpt * dv, n_vpt, st.x[2 * l], B, Lv, dv, s));
+        HIPCHK(E, launch_overwrite_rows(vpt_deep + (size_t)(l - 1) * n_vpt * dv, n_vpt, st.x[2 * l], B, Lv, dv, s, vmask(l)));
       } else {
         // reference quirk (trainers/mvlpt.py:71-83 has no `else`): the layer is skipped entirely
         st.skip[l] = 1;
@@ -901,7 +914,7 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
     if (l > 0 && E->v_ndeep > 0 && l <= E->v_ndeep) {
       ProfScope ps(E, s, PC_GLUE, 0, (double)B * n * dv * 10.0);
       HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt_deep + (size_t)(l - 1) * n * dv,
-                                          st.scale_dev, 1, s, xs));
+                                          st.scale_dev, 1, s, xs, E->vpt_mask ? E->vpt_mask + (size_t)l * B * n * dv : nullptr));
     }
     l_top = l - 1;
   } else {
@@ -916,12 +929,12 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
     if (l > 0 && E->v_ndeep > 0 && l <= E->v_ndeep) {
       ProfScope ps(E, s, PC_GLUE, 0, (double)B * n * dv * 10.0);
       HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt_deep + (size_t)(l - 1) * n * dv,
-                                          st.scale_dev, 1, s, xs));
+                                          st.scale_dev, 1, s, xs, E->vpt_mask ? E->vpt_mask + (size_t)l * B * n * dv : nullptr));
     }
   }
   if (n > 0) {
     ProfScope ps(E, s, PC_GLUE, 0, (double)B * n * dv * 4.0);
-    HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt, st.scale_dev, 0, s));
+    HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt, st.scale_dev, 0, s, 0, E->vpt_mask));
   }
   return 0;
 }

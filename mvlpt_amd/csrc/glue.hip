@@ -264,7 +264,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
                                                               const float* __restrict__ pos, const float* __restrict__ g,
                                                               const float* __restrict__ bt, const float* __restrict__ vpt,
-                                                              int n_vpt, float* __restrict__ x, int B, int G2, int d) {
+                                                              const float* __restrict__ vmask, int n_vpt, float* __restrict__ x, int B,
+                                                              int G2, int d) {
   const int lane = threadIdx.x & 63;
   const int L = 1 + n_vpt + G2;
   const size_t rows = (size_t)B * L, nw = (size_t)gridDim.x * 4;
@@ -287,6 +288,9 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __res
     for (int k = 0; k < NV; ++k) {
       const int c = (k * 64 + lane) * 4;
       v[k] = !ok[k] ? zero : (prompt || i == 0) ? *(const f32x4*)(src + c) : __builtin_nontemporal_load((const f32x4*)(src + c));
+      // vpt_dropout (trainers/mvlpt.py:424): the prompt rows are `expand`ed over the batch BEFORE the dropout, so every image has
+      // its own mask [B, n_vpt, d] (0 or 1 / (1 - p))
+      if (vmask && prompt && ok[k]) v[k] *= *(const f32x4*)(vmask + ((size_t)b * n_vpt + (i - 1)) * d + c);
     }
   };
   if (row < rows) load_row(row, cur);
@@ -326,13 +330,13 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __res
   }
 }
 hipError_t launch_assemble_tokens(const float* patch_emb, const float* cls, const float* pos, const float* g, const float* b,
-                                  const float* vpt, int n_vpt, float* x, int B, int G2, int d, hipStream_t s) {
+                                  const float* vpt, int n_vpt, float* x, int B, int G2, int d, hipStream_t s, const float* vmask) {
   if (d % 4 || d > 2048) return hipErrorInvalidValue;
   const size_t rows = (size_t)B * (1 + n_vpt + G2);
   const size_t want = (rows + 3) / 4;
   const dim3 grid((unsigned)(want < 2048 ? want : 2048)), block(256);
   const int nv = (d + 255) / 256;
-#define MVLPT_ASM_TOK(NV) hipLaunchKernelGGL(assemble_tokens_kernel<NV>, grid, block, 0, s, patch_emb, cls, pos, g, b, vpt, n_vpt, x, B, G2, d)
+#define MVLPT_ASM_TOK(NV) hipLaunchKernelGGL(assemble_tokens_kernel<NV>, grid, block, 0, s, patch_emb, cls, pos, g, b, vpt, vmask, n_vpt, x, B, G2, d)
   if (nv <= 2) MVLPT_ASM_TOK(2);
   else if (nv == 3) MVLPT_ASM_TOK(3);
   else if (nv == 4) MVLPT_ASM_TOK(4);
@@ -341,19 +345,22 @@ hipError_t launch_assemble_tokens(const float* patch_emb, const float* cls, cons
   return hipGetLastError();
 }
 
-__global__ void overwrite_rows_kernel(const float* __restrict__ rows, int n, float* __restrict__ x, int B, int L, int d) {
+__global__ void overwrite_rows_kernel(const float* __restrict__ rows, const float* __restrict__ vmask, int n, float* __restrict__ x, int B,
+                                      int L, int d) {
   const int d4 = d / 4;
   const size_t total = (size_t)B * n * d4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % d4), j = (int)((i / d4) % n), b = (int)(i / ((size_t)d4 * n));
-    *(f32x4*)(x + ((size_t)b * L + 1 + j) * d + c * 4) = *(const f32x4*)(rows + (size_t)j * d + c * 4);
+    f32x4 v = *(const f32x4*)(rows + (size_t)j * d + c * 4);
+    if (vmask) v *= *(const f32x4*)(vmask + ((size_t)b * n + j) * d + c * 4);      // per-image dropout mask of this layer's prompts
+    *(f32x4*)(x + ((size_t)b * L + 1 + j) * d + c * 4) = v;
   }
 }
-hipError_t launch_overwrite_rows(const float* rows, int n, float* x, int B, int L, int d, hipStream_t s) {
+hipError_t launch_overwrite_rows(const float* rows, int n, float* x, int B, int L, int d, hipStream_t s, const float* vmask) {
   if (n <= 0) return hipSuccess;
   const size_t total = (size_t)B * n * (d / 4);
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(overwrite_rows_kernel, dim3(grid), dim3(256), 0, s, rows, n, x, B, L, d);
+  hipLaunchKernelGGL(overwrite_rows_kernel, dim3(grid), dim3(256), 0, s, rows, vmask, n, x, B, L, d);
   return hipGetLastError();
 }
 
@@ -381,7 +388,7 @@ hipError_t launch_copy_rows_strided(const void* src, void* dst, int rows, size_t
 template <typename T>
 __global__ __launch_bounds__(1024) void reduce_prompt_rows_kernel(float* __restrict__ dx32, T* __restrict__ dx16, int B, int L, int d,
                                                                   int row0, int n, float* __restrict__ out, const float* scale_dev,
-                                                                  int zero_after, int split16) {
+                                                                  int zero_after, int split16, const float* __restrict__ vmask) {
   __shared__ f32x4 part[16][64];
   const int j = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -392,7 +399,8 @@ __global__ __launch_bounds__(1024) void reduce_prompt_rows_kernel(float* __restr
 #pragma unroll 8
     for (int b = wave; b < B; b += 16) {
       const size_t o = ((size_t)b * L + row0 + j) * d + c;
-      acc += *(const f32x4*)(dx32 + o);
+      if (vmask) acc += *(const f32x4*)(dx32 + o) * *(const f32x4*)(vmask + ((size_t)b * n + j) * d + c);   // back through the dropout
+      else acc += *(const f32x4*)(dx32 + o);
       if (zero_after) {
         *(f32x4*)(dx32 + o) = f32x4{0.f, 0.f, 0.f, 0.f};
         if (dx16) {
@@ -418,12 +426,12 @@ __global__ __launch_bounds__(1024) void reduce_prompt_rows_kernel(float* __restr
   }
 }
 hipError_t launch_reduce_prompt_rows(int dtype, float* dx32, void* dx16, int B, int L, int d, int row0, int n, float* out,
-                                     const float* scale_dev, int zero_after, hipStream_t s, int split16) {
+                                     const float* scale_dev, int zero_after, hipStream_t s, int split16, const float* vmask) {
   if (n <= 0) return hipSuccess;
   if (d % 4) return hipErrorInvalidValue;
   dim3 grid((d + 255) / 256, n), block(1024);
-  if (dtype == DT_F16) hipLaunchKernelGGL(reduce_prompt_rows_kernel<f16>, grid, block, 0, s, dx32, (f16*)dx16, B, L, d, row0, n, out, scale_dev, zero_after, split16);
-  else if (dtype == DT_BF16) hipLaunchKernelGGL(reduce_prompt_rows_kernel<bf16>, grid, block, 0, s, dx32, (bf16*)dx16, B, L, d, row0, n, out, scale_dev, zero_after, split16);
+  if (dtype == DT_F16) hipLaunchKernelGGL(reduce_prompt_rows_kernel<f16>, grid, block, 0, s, dx32, (f16*)dx16, B, L, d, row0, n, out, scale_dev, zero_after, split16, vmask);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL(reduce_prompt_rows_kernel<bf16>, grid, block, 0, s, dx32, (bf16*)dx16, B, L, d, row0, n, out, scale_dev, zero_after, split16, vmask);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -207,9 +207,10 @@ hipError_t launch_pack_weight_t(int dtype, const float* w, void* out, int rows, 
 hipError_t launch_patchify(int dtype, const void* image, int image_dtype, void* out, int B, int R, int P, int Kp, hipStream_t s);
 // tokens: row0 = LN(cls + pos0); rows 1..n = vpt; rest = LN(patch + pos)   (trainers/mvlpt.py:56-62)
 hipError_t launch_assemble_tokens(const float* patch_emb, const float* cls, const float* pos, const float* g, const float* b,
-                                  const float* vpt, int n_vpt, float* x, int B, int G2, int d, hipStream_t s);
+                                  const float* vpt, int n_vpt, float* x, int B, int G2, int d, hipStream_t s,
+                                  const float* vmask = nullptr /* [B, n_vpt, d] dropout mask of the prompt rows, or null */);
 // x[b, 1+j, :] = rows[j, :]   (deep prompt overwrite, trainers/mvlpt.py:78-82)
-hipError_t launch_overwrite_rows(const float* rows, int n, float* x, int B, int L, int d, hipStream_t s);
+hipError_t launch_overwrite_rows(const float* rows, int n, float* x, int B, int L, int d, hipStream_t s, const float* vmask = nullptr);
 // prompts (forward_coop + positional embedding, trainers/mvlpt.py:439-515, 107/112)
 hipError_t launch_assemble_prompts(const float* prefix, const float* suffix, const float* ctx, int ctx_per_class, int n_ctx,
                                    const int32_t* layout, const float* pos, float* x, int C, int L, int d, hipStream_t s);
@@ -221,7 +222,7 @@ hipError_t launch_copy_rows(const void* src, void* dst, const int32_t* idx, int 
 hipError_t launch_copy_rows_strided(const void* src, void* dst, int rows, size_t src_pitch, size_t dst_pitch, int row_bytes, hipStream_t s);
 // out[j,:] = inv_scale * sum_b dx[b, row0+j, :]; optionally zero those rows of dx32/dx16 afterwards
 hipError_t launch_reduce_prompt_rows(int dtype, float* dx32, void* dx16, int B, int L, int d, int row0, int n, float* out,
-                                     const float* scale_dev, int zero_after, hipStream_t s, int split16 = 0);
+                                     const float* scale_dev, int zero_after, hipStream_t s, int split16 = 0, const float* vmask = nullptr);
 // dctx (generic) [n,d] = inv_scale * sum_c dx[c, ctx_pos[c,j], :]  or (per class) [C,n,d]
 hipError_t launch_gather_ctx_grad(const float* dx, const int32_t* ctx_pos, int C, int L, int d, int n_ctx, int per_class,
                                   float* dctx, const float* scale_dev, hipStream_t s);

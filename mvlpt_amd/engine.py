@@ -111,6 +111,16 @@ class Engine:
         _lib.check(lib.mvlpt_set_precision(self.h, int(code)), self.h, "set_precision")
         self.precision = int(code)
 
+    def set_vpt_dropout(self, masks: Optional[torch.Tensor]) -> None:
+        """Per-image dropout masks of the visual prompt rows for the next image_fwd / image_bwd pair (include/mvlpt_hip.h:
+        mvlpt_set_vpt_dropout): fp32 [n_layers, B, n_vpt, width], or None to clear.  The engine keeps the tensor alive."""
+        if masks is not None:
+            masks = _req(masks, torch.float32, "vpt dropout masks")
+            if masks.dim() != 4 or masks.shape[-1] != self.arch.vision_width:
+                raise ValueError("vpt dropout masks must be [n_layers, B, n_vpt, vision_width]")
+        self._vpt_masks = masks
+        _lib.check(lib.mvlpt_set_vpt_dropout(self.h, _ptr(masks), 0 if masks is None else int(masks.shape[0])), self.h, "set_vpt_dropout")
+
     def set_ln_fold(self, mode: int, min_rows: int = 4096) -> None:
         """LayerNorm folding (include/mvlpt_hip.h: mvlpt_set_ln_fold): 0 off, 1 image tower, 2 both towers."""
         _lib.check(lib.mvlpt_set_ln_fold(self.h, int(mode), int(min_rows)), self.h, "set_ln_fold")
@@ -156,6 +166,9 @@ class Engine:
         if vpt is not None:
             vpt = _req(vpt, torch.float32, "vpt").reshape(-1, self.arch.vision_width)
             n_vpt = vpt.shape[0]
+        m = getattr(self, "_vpt_masks", None)
+        if m is not None and (m.shape[1] != B or m.shape[2] != n_vpt):
+            raise ValueError(f"vpt dropout masks are {tuple(m.shape)} but the batch has {B} images and {n_vpt} prompt tokens")
         if vpt_deep is not None:
             vpt_deep = _req(vpt_deep, torch.float32, "vpt_deep")
             n_deep = vpt_deep.shape[0]

@@ -202,26 +202,28 @@ class MultitaskVLPromptLearner(nn.Module):
         clip_imsize, cfg_imsize = arch.image_resolution, cfg.INPUT.SIZE[0]
         assert cfg_imsize == clip_imsize, f"cfg_imsize ({cfg_imsize}) must equal to clip_imsize ({clip_imsize})"
 
-        self.vpt_dropout = nn.Dropout(T.VPT.DROPOUT)
-        if T.VPT.DROPOUT != 0.0:
-            raise NotImplementedError("VPT.DROPOUT != 0 is not supported by the HIP path (default 0.0, train.py:139)")
+        self.vpt_dropout = nn.Dropout(T.VPT.DROPOUT)                                    # :165 (applied per image: CustomCLIP.forward)
         self.vpt_deep = T.VPT.DEEP
         self.vpt_embeddings = None
         self.vpt_embeddings_deep = None
         prompt_prefix = ""
         if vpt_n_ctx != 0:
-            if T.VPT.PROJECT > -1:
-                raise NotImplementedError("VPT.PROJECT > -1 is not supported (default -1 = Identity, train.py:140)")
-            self.vpt_proj = nn.Identity()
+            if T.VPT.PROJECT > -1:                                                      # :170-175
+                vpt_dim = T.VPT.PROJECT
+                self.vpt_proj = nn.Linear(vpt_dim, vpt_ctx_dim, dtype=dtype)
+                nn.init.kaiming_normal_(self.vpt_proj.weight, a=0, mode="fan_out")
+            else:
+                vpt_dim = vpt_ctx_dim
+                self.vpt_proj = nn.Identity()
             if T.VPT.CTX_INIT:
                 raise ValueError("CTX initiation scheme is not supported")            # :180-182
             ps = arch.vision_patch_size
-            val = math.sqrt(6. / float(3 * reduce(mul, (ps, ps), 1) + vpt_ctx_dim))     # :186
-            self.vpt_embeddings = nn.Parameter(torch.zeros(1, vpt_n_ctx, vpt_ctx_dim, dtype=dtype))
+            val = math.sqrt(6. / float(3 * reduce(mul, (ps, ps), 1) + vpt_dim))         # :186
+            self.vpt_embeddings = nn.Parameter(torch.zeros(1, vpt_n_ctx, vpt_dim, dtype=dtype))
             nn.init.uniform_(self.vpt_embeddings.data, -val, val)
             if self.vpt_deep:
                 self.vision_layers = arch.vision_layers
-                self.vpt_embeddings_deep = nn.Parameter(torch.zeros(arch.vision_layers - 1, vpt_n_ctx, vpt_ctx_dim, dtype=dtype))
+                self.vpt_embeddings_deep = nn.Parameter(torch.zeros(arch.vision_layers - 1, vpt_n_ctx, vpt_dim, dtype=dtype))
                 nn.init.uniform_(self.vpt_embeddings_deep.data, -val, val)
             prompt_prefix = "a photo of a "                                             # :201
 
@@ -656,8 +658,39 @@ class CustomCLIP(nn.Module):
         for entry in pre.values():
             torch.cuda.current_stream().wait_event(entry[1])
 
+    def prompt_learner_visual_prompts(self):
+        """(vpt, vpt_deep) as the image tower takes them: forward_mvlpt_proj, then vpt_proj (no dropout)."""
+        _, vpt_emb, vpt_emb_deep = self.prompt_learner.forward_mvlpt_proj(self.dtype)
+        if vpt_emb is not None:
+            vpt_emb = self.prompt_learner.vpt_proj(vpt_emb)
+            vpt_emb_deep = None if vpt_emb_deep is None else self.prompt_learner.vpt_proj(vpt_emb_deep)
+        return vpt_emb, vpt_emb_deep
+
+    def vpt_dropout_masks(self, B):
+        """Outcome of `vpt_dropout` on the prompt rows of every prompted layer, drawn in the reference's order (the shallow prompts
+        in forward_vpt, trainers/mvlpt.py:424, then layer 1, 2, ... in ImageEncoder.forward, :77), each on the rows already expanded
+        over the batch: [n_layers, B, n_vpt, width] of 0 or 1 / (1 - p), or None when nothing is dropped (p = 0, eval mode)."""
+        pl = self.prompt_learner
+        p = float(pl.vpt_dropout.p)
+        if pl.vpt_embeddings is None or p == 0.0 or not pl.training:
+            return None
+        if getattr(self, "_vpt_masks_override", None) is not None:      # tests: the masks the reference drew
+            return self._vpt_masks_override
+        n_layers = 1 + (pl.vpt_embeddings_deep.shape[0] if (pl.vpt_deep and pl.vpt_embeddings_deep is not None) else 0)
+        dev = pl.vpt_embeddings.device
+        ones = torch.ones(B, pl.vpt_n_ctx, self.clip_model.arch.vision_width, device=dev)
+        return torch.stack([pl.vpt_dropout(ones) for _ in range(n_layers)])
+
     def forward(self, image, task=None):
         coop_emb, vpt_emb, vpt_emb_deep = self.prompt_learner.forward_mvlpt_proj(self.dtype)
+        if vpt_emb is not None:
+            # vpt_proj (VPT.PROJECT > -1: a trainable Linear, else Identity) in front of the shallow and of every deep prompt
+            # (:424, :77): a few hundred FLOPs on [n, vpt_dim] rows, left to torch autograd like forward_mvlpt_proj
+            proj = self.prompt_learner.vpt_proj
+            vpt_emb = proj(vpt_emb)
+            if vpt_emb_deep is not None:
+                vpt_emb_deep = proj(vpt_emb_deep)
+            self.engine.set_vpt_dropout(self.vpt_dropout_masks(image.shape[0]))
         lo = hi = None
         if self.multi_task_label_pertask:
             t = task.cpu().long() if torch.is_tensor(task) else torch.as_tensor(task).long()

@@ -4,6 +4,7 @@ Run in the build container only (needs /root/reference; see oracle/ref_shim.py):
 
     python oracle/make_golden.py            # all fixtures
     python oracle/make_golden.py tiny       # only the tiny-arch ones
+    python oracle/make_golden.py vptopt     # VPT.PROJECT / VPT.DROPOUT cases (tiny arch)
 
 The reference's `trainers.mvlpt.CustomCLIP` (trainers/mvlpt.py:517-583) is instantiated on a
 `clip.model.CLIP` (clip/model.py:239-322) whose weights come from OUR deterministic generator
@@ -87,6 +88,20 @@ def run_case(mv, clip_model, *, name, image_size, classnames, B, case_seed, soft
         for n_, p in pl.named_parameters():
             if n_.startswith("mvlpt_proj") and p.dim() == 1 and float(p.abs().sum()) == 0.0:
                 p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    # VPT.DROPOUT > 0: record what `vpt_dropout` (trainers/mvlpt.py:165) does to the prompt rows of every prompted layer — the
+    # masks are part of the fixture (the HIP path is given the same ones; a mask is data, 0 or 1 / (1 - p))
+    drop_masks = []
+    if float(cfgkw.get("vpt_dropout", 0.0)) > 0.0:
+        p_drop = float(cfgkw["vpt_dropout"])
+
+        class _RecordingDropout(torch.nn.Module):
+            def forward(self, x):
+                if not self.training:
+                    return x
+                m = F.dropout(torch.ones_like(x), p_drop, training=True)
+                drop_masks.append(m.detach().clone())
+                return x * m
+        pl.vpt_dropout = _RecordingDropout()
     C = len(classnames)
     g = torch.Generator().manual_seed(case_seed + 1000)    # inputs have their own stream
     image = torch.randn(B, 3, image_size, image_size, generator=g)
@@ -117,6 +132,8 @@ def run_case(mv, clip_model, *, name, image_size, classnames, B, case_seed, soft
     loss = F.cross_entropy(logits, lab)
     loss.backward()
 
+    if drop_masks:
+        cc.eval()                                          # the stored tower features are the evaluation-mode ones
     with torch.no_grad():
         coop_emb, vpt_emb, vpt_deep_emb = pl.forward_mvlpt_proj(cc.dtype)
         img_feat = cc.image_encoder(image, vpt_emb, vpt_deep_emb)
@@ -137,6 +154,11 @@ def run_case(mv, clip_model, *, name, image_size, classnames, B, case_seed, soft
         "out_image_features": img_feat.numpy(), "out_text_features": txt_feat.numpy(),
         "case_seed": np.int64(case_seed),
     }
+    if drop_masks:
+        d["vpt_dropout_masks"] = torch.stack(drop_masks).numpy()      # [n_layers, B, n_vpt, width]
+        d["meta_vpt_dropout"] = np.float64(cfgkw["vpt_dropout"])
+    if int(cfgkw.get("vpt_project", -1)) > -1:
+        d["meta_vpt_project"] = np.int64(cfgkw["vpt_project"])
     if task is not None:
         d["task"] = task.numpy().astype(np.int64)
         d["task_start"] = cc.class_index_pertask_start.numpy().astype(np.int64)
@@ -183,6 +205,18 @@ def make_tiny(mv, cm):
              cut_contextlen=True, **common)
     run_case(mv, clip_model, name="tiny_upt_cut", case_seed=22, coop_n_ctx=4, vpt_n_ctx=2, vpt_deep=True,
              project_dim=64, cut_contextlen=True, **common)
+
+
+def make_vpt_options(mv, cm):
+    """`vptopt`: TRAINER.MVLPT.VPT.PROJECT > -1 (a trainable Linear in front of the visual prompts, trainers/mvlpt.py:170-175) and
+    VPT.DROPOUT > 0 (:165, per-image masks).  Separate target: the other tiny fixtures are not regenerated."""
+    arch = ARCHS["tiny"]
+    clip_model, _ = build_ref_clip(cm, arch, TINY_SEED)
+    common = dict(image_size=arch.image_resolution, classnames=CLASSNAMES[:5], B=4)
+    run_case(mv, clip_model, name="tiny_vpt_project", case_seed=41, vpt_n_ctx=2, vpt_deep=True, vpt_project=24, **common)
+    run_case(mv, clip_model, name="tiny_vpt_project_dropout", case_seed=42, vpt_n_ctx=3, vpt_deep=True, vpt_project=24,
+             vpt_dropout=0.25, **common)
+    run_case(mv, clip_model, name="tiny_vpt_shallow_dropout", case_seed=43, vpt_n_ctx=2, vpt_deep=False, vpt_dropout=0.5, **common)
 
 
 def make_train_steps(mv, clip_model, arch):
@@ -416,6 +450,8 @@ def main():
         make_large(mv, cm)
     if "coop" in which:
         make_coop_trainer(cm)
+    if "vptopt" in which:
+        make_vpt_options(mv, cm)
 
 
 if __name__ == "__main__":

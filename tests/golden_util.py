@@ -11,6 +11,8 @@ TINY_CASES = ["tiny_coop_end", "tiny_coop_middle", "tiny_coop_front", "tiny_coop
               "tiny_vpt_shallow", "tiny_vpt_deep", "tiny_upt", "tiny_upt_samedim", "tiny_upt_cut",
               "tiny_task_mask", "tiny_soft_labels",
               "tiny_upt_mask_soft"]        # UPT + per-task logit mask + soft multi-hot labels together (BASELINE cfg4 / cfg5 shape)
+# TRAINER.MVLPT.VPT.PROJECT > -1 / VPT.DROPOUT > 0 (oracle/make_golden.py vptopt): carry `vpt_proj.*` parameters and the masks
+VPT_OPTION_CASES = ["tiny_vpt_project", "tiny_vpt_project_dropout", "tiny_vpt_shallow_dropout"]
 FULL_CASES = ["full_vitb32_coop_end", "full_vitb16_coop_middle", "full_vitb16_vpt_deep", "full_vitb16_upt_cut",
               "full_vitl14_336_upt_cut"]
 

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.golden_util import TINY_CASES, case_grads, case_params, load_npz, t, tiny_state_dict
+from tests.golden_util import TINY_CASES, VPT_OPTION_CASES, case_grads, case_params, load_npz, t, tiny_state_dict
 
 pytestmark = pytest.mark.gpu
 
@@ -39,6 +39,8 @@ def cfg_for_case(case, image_size):
     T.COOP.CLASS_TOKEN_POSITION = str(case["meta_position"])
     T.VPT.N_CTX = int(case["meta_vpt_n_ctx"])
     T.VPT.DEEP = bool(case["meta_vpt_deep"]) or T.VPT.N_CTX == 0
+    T.VPT.PROJECT = int(case.get("meta_vpt_project", -1))
+    T.VPT.DROPOUT = float(case.get("meta_vpt_dropout", 0.0))
     cfg.TRAINER.CUT_CONTEXTLEN = bool(case["meta_cut"])
     cfg.INPUT.SIZE = (image_size, image_size)
     cfg.DATASET.MULTITASK_LABEL_PERTASK = "task" in case
@@ -75,7 +77,10 @@ def build_model(case, clip, image_size, token_prefix, token_suffix):
     missing = pl.load_state_dict(sd, strict=True)
     assert np.array_equal(pl.layout.numpy(), case["layout"]), "layout table must be bit-exact"
     assert np.array_equal(pl.eot.numpy().astype(np.int64), case["eot"])
-    return model.to(clip.device)
+    model = model.to(clip.device)
+    if "vpt_dropout_masks" in case:        # the dropout outcome the reference drew is part of the fixture
+        model._vpt_masks_override = t(case["vpt_dropout_masks"]).to(clip.device)
+    return model
 
 
 def run_case(case, model, image, tol, gtol):
@@ -128,6 +133,32 @@ def test_tiny_case_fp16(name, tiny_clip_fp16):
     print(f"{name}: logits {err:.2e} grads {max(worst.values()):.2e}")
     if name in MARGIN_GUARD:
         assert worst["ctx"] < MARGIN_GUARD[name], f"{name}: ctx gradient error {worst['ctx']:.2e} ate the parity margin"
+
+
+@pytest.mark.parametrize("name", VPT_OPTION_CASES)
+def test_vpt_project_and_dropout_fp16(name, tiny_clip_fp16):
+    """VPT.PROJECT > -1 (trainable `vpt_proj` Linear, trainers/mvlpt.py:170-175) and VPT.DROPOUT > 0 (:165: per-image masks on the
+    prompt rows of every prompted layer, here the ones the reference drew): logits, loss and every gradient — `vpt_proj.weight` /
+    `.bias` included — within the north_star 1e-3; in evaluation mode the dropout is the identity and the logits are deterministic."""
+    case = load_npz(name)
+    model = build_model(case, tiny_clip_fp16, 32, t(case["token_prefix"]), t(case["token_suffix"]))
+    err, worst = run_case(case, model, t(case["image"]), TOL_TINY_FP16, GRAD_TOL_FP16)
+    print(f"{name}: logits {err:.2e} grads {max(worst.values()):.2e}")
+    model.eval()
+    with torch.no_grad():
+        a = model(t(case["image"]).to(tiny_clip_fp16.device)).cpu()
+        b = model(t(case["image"]).to(tiny_clip_fp16.device)).cpu()
+        img = model.engine.image_fwd(t(case["image"]).to(tiny_clip_fp16.device), *model.prompt_learner_visual_prompts())
+    assert torch.equal(a, b)
+    ref = t(case["out_image_features"])                    # (stored in evaluation mode)
+    assert float((img.cpu() - ref).abs().max()) / float(ref.abs().max()) < TOL_TINY_FP16
+    if "vpt_dropout_masks" in case:                        # ... and without the override the masks are drawn on the device: right shape / values
+        model.train()
+        model._vpt_masks_override = None
+        m = model.vpt_dropout_masks(4)
+        p = float(case["meta_vpt_dropout"])
+        assert m.shape == case["vpt_dropout_masks"].shape and m.is_cuda
+        assert set(torch.unique(m).tolist()) <= {0.0, float(torch.tensor(1.0) / (1.0 - p))}
 
 
 @pytest.fixture(scope="module")

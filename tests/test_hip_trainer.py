@@ -174,8 +174,12 @@ def test_lookahead_reaches_a_plain_dassl_loop(tmp_path):
     assert not tr.model._prefetched and tr._parsed_ahead is None and tr.next_batch is None
 
 
-def test_three_reference_train_steps_on_the_hip_engine(tmp_path):
-    """f2 pin on the GPU: MVLPT (HIP forward/backward + torch SGD + warm-up/cosine schedule, driven through run_epoch)
+@pytest.mark.parametrize("prec", ["fp16", "amp", "fp32"])
+def test_three_reference_train_steps_on_the_hip_engine(tmp_path, prec):
+    """TRAINER.MVLPT.PREC (trainers/mvlpt.py:835-836, 919-926): `amp` — autocast + GradScaler in the reference — is this engine's default
+    mode (fp32 master prompts, 16-bit MFMA inputs, gradient scaling inside the backward; no GradScaler object: `trainer.scaler is
+    None`), `fp32` runs every tower on split operands; all three reproduce the reference's fp32 train fixture.
+    f2 pin on the GPU: MVLPT (HIP forward/backward + torch SGD + warm-up/cosine schedule, driven through run_epoch)
     reproduces the reference's three-step train fixture: losses within 1e-3, every parameter's UPDATE within 2e-3 of its
     max (the gradients themselves are within 1e-3; momentum carries three of them)."""
     from mvlpt_amd.model import PretokenizedPrompts
@@ -185,8 +189,10 @@ def test_three_reference_train_steps_on_the_hip_engine(tmp_path):
     z = load_npz("tiny_train_steps")
     cfg = fixture_cfg(z)
     cfg.OUTPUT_DIR = str(tmp_path)
+    cfg.TRAINER.MVLPT.PREC = prec
     dm = SyntheticDataManager(cfg, 5, 1, device="cuda", seed=3)
     dm.pretokenized = PretokenizedPrompts(t(z["tokenized_prompts"]), z["name_lens"].tolist())
     tr = MVLPT(cfg, dm=dm, clip_state_dict=tiny_state_dict())
+    assert tr.scaler is None
     losses, lrs, params = run_three_steps(tr, z, "cuda")
     check_against_fixture(z, losses, lrs, params, loss_tol=1e-3, delta_tol=2e-3)

@@ -192,3 +192,26 @@ def test_lookahead_loader_semantics():
     it.close()                                                           # a hook broke out of the loop
     assert o.next_batch is None
     assert list(LookAheadLoader(Loader([]), o)) == [] and o.next_batch is None
+
+
+@pytest.mark.parametrize("name", ["tiny_vpt_project", "tiny_vpt_project_dropout", "tiny_vpt_shallow_dropout"])
+def test_vpt_project_and_dropout_host_logic_on_the_oracle_engine(name):
+    """The host side of VPT.PROJECT / VPT.DROPOUT (model.py: `vpt_proj` through torch autograd, per-image masks handed to the
+    engine) around the CPU-oracle engine, against the reference fixture: the same CustomCLIP code path the HIP engine sits under."""
+    import numpy as np
+    from tests.fake_engine import OracleFrozenCLIP
+    from tests.golden_util import case_grads, load_npz, t, tiny_state_dict
+    from tests.test_hip_model import build_model
+    from mvlpt_amd.weights import ARCHS
+    case = load_npz(name)
+    clip = OracleFrozenCLIP(tiny_state_dict(), ARCHS["tiny"])
+    model = build_model(case, clip, 32, t(case["token_prefix"]), t(case["token_suffix"]))
+    logits = model(t(case["image"]))
+    loss = model.cross_entropy(logits, t(case["label"]))
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().numpy(), case["out_logits"], rtol=2e-4, atol=1e-5)
+    G = case_grads(case)
+    got = {n: p.grad for n, p in model.prompt_learner.named_parameters()}
+    assert set(got) == set(G)
+    for k, g in G.items():
+        assert float((got[k] - g).abs().max()) / (float(g.abs().max()) + 1e-12) < 5e-4, k

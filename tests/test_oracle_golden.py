@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import clip_oracle as O
-from tests.golden_util import (TINY_CASES, case_grads, case_params, load_npz, t, tiny_state_dict)
+from tests.golden_util import (TINY_CASES, VPT_OPTION_CASES, case_grads, case_params, load_npz, t, tiny_state_dict)
 
 RTOL = 2e-4   # fp32 reduction-order differences through 2-3 transformer layers
 ATOL = 2e-6
@@ -28,10 +28,12 @@ def run_oracle_on_case(case, sd, image, token_prefix, token_suffix, vision_heads
         sd, image=image, label=label, vision_heads=vision_heads, text_heads=text_heads,
         token_prefix=token_prefix, token_suffix=token_suffix, eot=t(case["eot"]), layout=layout,
         ctx=P.get("ctx"), vpt=P.get("vpt_embeddings"), vpt_deep=P.get("vpt_embeddings_deep"),
-        proj_params=proj or None, n_ctx=n_ctx, n_vpt=n_vpt, mask=mask), layout
+        proj_params=proj or None, n_ctx=n_ctx, n_vpt=n_vpt, mask=mask,
+        vpt_proj=({k[len("vpt_proj."):]: v for k, v in P.items() if k.startswith("vpt_proj.")} or None),
+        vpt_masks=(t(case["vpt_dropout_masks"]) if "vpt_dropout_masks" in case else None)), layout
 
 
-@pytest.mark.parametrize("name", TINY_CASES)
+@pytest.mark.parametrize("name", TINY_CASES + VPT_OPTION_CASES)
 def test_tiny_case_matches_reference(name):
     case = load_npz(name)
     sd = tiny_state_dict()
