@@ -85,14 +85,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   const int b_remap = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (b >> 3);
   // Tile enumeration: N-fastest (the tiles an XCD runs concurrently share 1-2 A panels).  A grouped, weight-resident
   // enumeration was measured and was not faster (A panels are then re-read from the Infinity Cache once per group).
-  // GemmArgs::nblk > 1 (256x256 geometry, wide N): the N tiles are walked in `nblk` column blocks, ALL row tiles of one block
-  // before the next, so that a block's share of the weight stays in the XCD's L2 while A streams (once per block)
-  const int nbw = g.nblk > 1 ? tilesN / g.nblk : tilesN;      // N tiles per column block (nblk divides tilesN)
-  const int per_blk = ((M + BM_ - 1) / BM_) * nbw;
-  auto tile_mn = [&](int t, int& tm, int& tn) {
-    const int blk = t / per_blk, r = t - blk * per_blk;
-    tm = r / nbw; tn = blk * nbw + (r - tm * nbw);
-  };
+  auto tile_mn = [&](int t, int& tm, int& tn) { tm = t / tilesN; tn = t - tm * tilesN; };
   auto tile_of = [&](int round) -> int {
     const int base = round * G;
     return base + ((base + G <= ntiles) ? b_remap : b);   // ragged last round: plain order keeps XCDs balanced
@@ -104,25 +97,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   const int scol = ((lane & 7) ^ srow) * 8;
   const T* ap[A_IT];
   const T* bp[B_IT];
-  // L2 prefetch (256x256 geometry, single operands; GemmArgs::pf_off): the first touch of an A K-stage is an L2 miss in every XCD
-  // (the tiles that share an A panel run in lock-step and all wait for the same fill), and with a 2-deep ring the miss latency
-  // (~2 300 cycles under load, tools/duo_trace.py) IS the stage time.  Each thread therefore touches one 128-byte line of the stage
-  // AFTER the one being requested (waves 0-3: the 256 A rows, 4-7: the 256 B rows) with a 4-byte LDS-DMA into a dummy region: no
-  // register to protect, and the counted wait at the end of the stage leaves it in flight.
-  constexpr bool CAN_PF = BM_ == 256 && BN_ == 256 && NW == 8 && NS == 2 && !MIXED;
-  [[maybe_unused]] const T* pfp = nullptr;
-  [[maybe_unused]] bool pf_issued = false;
   auto set_ptrs = [&](int t) {
     int tm, tn;
     tile_mn(t, tm, tn);
     const int m0 = tm * BM_, n0 = tn * BN;
-    if constexpr (CAN_PF) {
-      if (g.pf_off) {
-        int r = (wave & 3) * 64 + lane;
-        if (wave < 4) { r += m0; r = r < M ? r : M - 1; pfp = A + (size_t)r * lda; }
-        else { r += n0; r = r < N ? r : N - 1; pfp = Bt + (size_t)r * ldb; }
-      }
-    }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       int ar = m0 + (i * NW + wave) * 8 + srow; ar = ar < M ? ar : M - 1;   // edge rows are re-read, never stored
@@ -178,14 +156,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
       lt = tile_of(++lround);
       if (lt < ntiles) set_ptrs(lt);
     }
-    if constexpr (CAN_PF) {
-      pf_issued = false;
-      if (g.pf_off && lt < ntiles) {      // the stage the NEXT request will fetch
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pfp + lkt * BK),
-                                         (__attribute__((address_space(3))) void*)(smem + g.pf_off + wave * 256), 4, 0, 0);
-        pf_issued = true;
-      }
-    }
     return true;
   };
 
@@ -212,8 +182,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
         if (skip_stores) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS + ST_MIN_) : "memory"); return; }
       }
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    } else if (CAN_PF && pf_issued) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // the prefetch behind the request stays in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   wait_stage(n_issued - 1, false);
   __builtin_amdgcn_s_barrier();
@@ -255,7 +224,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
       // vmcnt retires in order and counts stores: right after an epilogue the youngest operations are its ST_MIN
       // global stores followed by the DMA just issued, so allowing ST_MIN + LOADS operations in flight still
       // guarantees the older DMA has landed without making the wave wait for its own output stores (NS == 3 only).
-      if constexpr (CAN_PF) { if (!issued) pf_issued = false; }
       wait_stage(n_issued - (n_done + 2), stores_pending && NS == 3 && issued);
       MVLPT_TR(5);
       stores_pending = false;
@@ -997,24 +965,13 @@ static hipError_t launch_geo_m(const GemmArgs& g, int wg_per_cu, hipStream_t s, 
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS + (LDS + XLDS_BYTES_WIDE <= 160 * 1024 ? XLDS_BYTES_WIDE : XLDS_BYTES) + (LDS + XLDS_BYTES_WIDE + 2048 <= 160 * 1024 ? 2048 : 0));
+                              LDS + (LDS + XLDS_BYTES_WIDE <= 160 * 1024 ? XLDS_BYTES_WIDE : XLDS_BYTES));
     attr_set = true;
   }
   // LayerNorm folding: 16 KiB behind the ring (the consumer's row partials / the producer's per-tile column-block sums)
-  int lds = LDS + (epi_folds(EPI) ? xlds_bytes(g.fold_ntp) : (EPI == EPI_RESID32_LN ? XLDS_BYTES : 0));
+  const int lds = LDS + (epi_folds(EPI) ? xlds_bytes(g.fold_ntp) : (EPI == EPI_RESID32_LN ? XLDS_BYTES : 0));
   if (lds > 160 * 1024) return hipErrorInvalidValue;      // (launch_one keeps 8-slot consumers off the 3-deep 256x128 ring)
-  GemmArgs ga = g;
-  static const int pf = getenv("MVLPT_GEMM_PF") ? atoi(getenv("MVLPT_GEMM_PF")) : 0;      // measured: image tower 10.49 -> 10.87 ms (NOTES): off
-  // weight-resident column blocks (experiment): MVLPT_GEMM_WBLK = bytes of weight per block (0: off)
-  static const long wblk = getenv("MVLPT_GEMM_WBLK") ? atol(getenv("MVLPT_GEMM_WBLK")) : 0;
-  if (wblk > 0 && BM_ == 256 && BN_ == 256 && g.a_split == 0) {
-    const int tn = g.N / 256;
-    const long wbytes = (long)g.N * g.K * 2;
-    for (int nb = 2; nb <= tn; ++nb)
-      if (tn % nb == 0 && wbytes / nb <= wblk) { ga.nblk = nb; break; }
-    if (wbytes <= wblk) ga.nblk = 0;
-  }
-  if (pf && BM_ == 256 && BN_ == 256 && NW == 8 && NS == 2 && !MIXED && g.a_split == 0 && lds + 2048 <= 160 * 1024) { ga.pf_off = lds; lds += 2048; }
+
   int cus = stream_cus(s);
 #ifdef MVLPT_DEBUG_CUS
   if (getenv("MVLPT_DBG_CUS")) cus = atoi(getenv("MVLPT_DBG_CUS"));      // CU-scaling measurement, debug builds only
@@ -1025,7 +982,7 @@ static hipError_t launch_geo_m(const GemmArgs& g, int wg_per_cu, hipStream_t s, 
   static const int maxtiles = getenv("MVLPT_GEMM_MAXTILES") ? atoi(getenv("MVLPT_GEMM_MAXTILES")) : 0;
   if (maxtiles > 0 && (tiles + maxtiles - 1) / maxtiles > resident) resident = (tiles + maxtiles - 1) / maxtiles;
   hipExtLaunchKernelGGL((gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), lds, s,
-                        ea, eb, 0, ga);
+                        ea, eb, 0, g);
   return hipGetLastError();
 }
 template <typename T, int EPI, int BM_, int BN_, int NW, int NS>

@@ -81,8 +81,6 @@ struct GemmArgs {
   const float* fold_part = nullptr;
   const float* fold_colsum = nullptr;
   int fold_ntp = 0, fold_nt = 0;
-  int nblk = 0;                 // set by the launcher: column blocks of the tile walk (0 / 1: N-fastest over the whole width)
-  int pf_off = 0;               // set by the launcher: LDS offset of the 2 KiB dummy region of the L2 prefetch (0: no prefetch)
 #ifdef MVLPT_GEMM_TRACE
   long long* trace = nullptr;   // debug builds only: per-wave (point id << 56 | s_memtime) records of workgroup 0
 #endif

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Throughput of the BASELINE.json / SURVEY §8(d) configurations on one GPU (no CPU baseline, no kernel timing).
-run() { echo -n "$* : "; python bench.py --no-cpu-baseline --no-kernel-timing "$@" 2>/dev/null | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], 'img/s', j['ms_per_step'], 'ms')"; }
+run() { echo -n "$* : "; python bench.py --no-cpu-baseline --no-kernel-timing --no-secondary "$@" 2>/dev/null | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], 'img/s', j['ms_per_step'], 'ms')"; }
 run --arch ViT-B/32 --batch 32 --steps 30
 run
 run --cut

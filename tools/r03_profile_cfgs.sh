@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 TAG=${1:-r03}; O=gpurun_out/$TAG; mkdir -p $O
 prof() {  # name, bench args...
   local name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_$name -o t -- python bench.py --no-cpu-baseline --no-kernel-timing "$@" > $O/${name}.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_$name -o t -- python bench.py --no-cpu-baseline --no-kernel-timing --no-secondary "$@" > $O/${name}.log 2>&1
   grep "^{\"metric" $O/${name}.log | tail -1 > $O/${name}_line_under_rocprof.json
   python tools/rocpd_summary.py $(ls $O/trace_$name/*.db | head -1) > $O/${name}_kernel_stats.md
   rm -rf $O/trace_$name
