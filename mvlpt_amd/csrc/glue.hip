@@ -731,16 +731,17 @@ hipError_t launch_cross_entropy(const float* logits, const void* labels, int lab
 }
 
 // d imn = scale * (dlogits*mask) txn ; d txn = scale * (dlogits*mask)^T imn ; then through x/||x||.
-// One workgroup per output row (image b / class c); its 4 waves split the reduction axis (classes / images), every
-// lane owns 8 consecutive feature columns (e <= 1024 = 2 x 64 lanes x 8), partial rows are combined through LDS.
+// One workgroup per output row (image b / class c); its 8 waves split the reduction axis (classes / images: 32 dependent row loads
+// per wave at B = 256 instead of 64 with four waves — the kernel is a latency chain, 36 -> ~20 us stand-alone), every
+// lane owns 8 consecutive feature columns (e <= 1024 = 2 x 64 lanes x 8), partial rows are combined through LDS in wave order.
 template <bool IMG>
-__global__ __launch_bounds__(256) void logits_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ imn,
+__global__ __launch_bounds__(512) void logits_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ imn,
                                                          const float* __restrict__ txn, const float* __restrict__ norm,
                                                          float scale, const int32_t* __restrict__ lo,
                                                          const int32_t* __restrict__ hi, float* __restrict__ dout,
                                                          int B, int C, int e) {
-  __shared__ float part[4][1024];
-  __shared__ float red[4];
+  __shared__ float part[8][1024];
+  __shared__ float red[8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x;                       // b (IMG) or c
   const float* other = IMG ? txn : imn;             // rows of the other side, indexed by the reduction index
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(256) void logits_bwd_kernel(const float* __restrict
   f32x4 acc[2][2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) { acc[k][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int r = wave; r < nred; r += 4) {
+  for (int r = wave; r < nred; r += 8) {
     const int b = IMG ? row : r, c = IMG ? r : row;
     if (lo && !(c >= lo[b] && c < hi[b])) continue;     // multiplicative 0/1 task mask
     const float w = scale * dl[(size_t)b * C + c];
@@ -769,21 +770,24 @@ __global__ __launch_bounds__(256) void logits_bwd_kernel(const float* __restrict
     if (i < e) { *(f32x4*)&part[wave][i] = acc[k][0]; *(f32x4*)&part[wave][i + 4] = acc[k][1]; }
   }
   __syncthreads();
-  float g[4], dot = 0.f;
+  float g[2], dot = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = threadIdx.x + k * 256;
+  for (int k = 0; k < 2; ++k) {
+    const int i = threadIdx.x + k * 512;
     g[k] = 0.f;
-    if (i < e) { g[k] = part[0][i] + part[1][i] + part[2][i] + part[3][i]; dot += g[k] * self[i]; }
+    if (i < e) {
+      g[k] = ((part[0][i] + part[1][i]) + (part[2][i] + part[3][i])) + ((part[4][i] + part[5][i]) + (part[6][i] + part[7][i]));
+      dot += g[k] * self[i];
+    }
   }
   dot = wave_sum(dot);
   if (lane == 0) red[wave] = dot;
   __syncthreads();
-  dot = red[0] + red[1] + red[2] + red[3];
+  dot = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
   const float inv = 1.0f / norm[row];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = threadIdx.x + k * 256;
+  for (int k = 0; k < 2; ++k) {
+    const int i = threadIdx.x + k * 512;
     if (i < e) dout[(size_t)row * e + i] = (g[k] - self[i] * dot) * inv;
   }
 }
@@ -791,8 +795,8 @@ hipError_t launch_logits_bwd(const float* dlogits, const float* imn, const float
                              float scale, const int32_t* lo, const int32_t* hi, float* dimg, float* dtxt, int B, int C, int e,
                              hipStream_t s) {
   if (e > 1024 || e % 8) return hipErrorInvalidValue;
-  if (dimg) hipLaunchKernelGGL(logits_bwd_kernel<true>, dim3(B), dim3(256), 0, s, dlogits, imn, txn, inorm, scale, lo, hi, dimg, B, C, e);
-  if (dtxt) hipLaunchKernelGGL(logits_bwd_kernel<false>, dim3(C), dim3(256), 0, s, dlogits, imn, txn, tnorm, scale, lo, hi, dtxt, B, C, e);
+  if (dimg) hipLaunchKernelGGL(logits_bwd_kernel<true>, dim3(B), dim3(512), 0, s, dlogits, imn, txn, inorm, scale, lo, hi, dimg, B, C, e);
+  if (dtxt) hipLaunchKernelGGL(logits_bwd_kernel<false>, dim3(C), dim3(512), 0, s, dlogits, imn, txn, tnorm, scale, lo, hi, dtxt, B, C, e);
   return hipGetLastError();
 }
 
