@@ -51,20 +51,15 @@ constexpr int TR_MAX = 2048;
 // the tile list in rounds and keep the LDS-DMA pipeline running ACROSS tile boundaries (the first K-stages of the
 // next tile are in flight while the current tile finishes and its epilogue is stored), so the short-K GEMMs of
 // this path (K = 768 / 512) do not pay a load bubble per tile.
-template <typename T, int EPI, int BM_, int BN_, int NW, int NS, bool MIXED, int BK_ = BK>
+template <typename T, int EPI, int BM_, int BN_, int NW, int NS, bool MIXED>
 __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2) void gemm_bt_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using v8 = typename Vec<T>::v8;
   constexpr int BN = BN_;
   constexpr int WCN = BN_ / 64, WCM = NW / WCN;       // waves along N / M
   constexpr int WMF = BM_ / WCM / 16;                 // 16-row A fragments per wave (4: 64x64 wave tile, 8: 128x64)
-  // BK_ = 32 (256x256 geometry only, NS = 4): 32-deep K-stages of 32 KiB in a 4-deep ring — the same 128 KiB of LDS as two 64-deep
-  // stages, but THREE stages (96 KiB) in flight instead of one (64 KiB); twice the stage barriers
-  static_assert(BK_ == 64 || (BK_ == 32 && !MIXED && NS == 4 && BM_ == 256 && BN_ == 256 && NW == 8), "32-deep stages: 256x256, 4-deep ring, single operands");
-  constexpr int ROWB = BK_ * 2;                       // bytes of a tile row in a stage
-  constexpr int RPP = 1024 / ROWB;                    // rows per 1-KiB LDS-DMA piece (8 / 16)
-  constexpr int A_BYTES = BM_ * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_IT = BM_ / RPP / NW, B_IT = BN / RPP / NW, LOADS = A_IT + B_IT;
+  constexpr int A_BYTES = BM_ * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_IT = BM_ / 8 / NW, B_IT = BN / 8 / NW, LOADS = A_IT + B_IT;
   constexpr int ST_MIN_ = (WMF / 4) * ((epi_base(EPI) == EPI_STORE16 || epi_base(EPI) == EPI_GELU) ? 8 : 16);
   constexpr bool CAN_FOLD = epi_folds(EPI);
   [[maybe_unused]] char* const xlds = smem + NS * STAGE;        // LayerNorm folding: XLDS_BYTES(_WIDE) behind the ring (when launched with them)
@@ -98,10 +93,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
 
   // ---- staging: thread -> (row, 16B chunk) of a 1 KiB LDS slab (8 rows x 128 B); the LDS image is lane-linear,
   //      so the bank swizzle is applied to the SOURCE column: LDS chunk c of row r holds source chunk c ^ (r & 7)
-  // (32-deep stages: 16 rows x 64 B per piece, LDS chunk p of row r holds source chunk p ^ SW32[(r >> 2) & 3] — with
-  // SW32 = {0, 2, 3, 1} every 16-lane group of a ds_read_b128 fragment read covers all 16 slots of the 256-B bank row)
-  const int srow = BK_ == 64 ? lane >> 3 : lane >> 2;
-  const int scol = BK_ == 64 ? ((lane & 7) ^ srow) * 8 : ((lane & 3) ^ ((0x78 >> (2 * ((srow >> 2) & 3))) & 3)) * 8;
+  const int srow = lane >> 3;
+  const int scol = ((lane & 7) ^ srow) * 8;
   const T* ap[A_IT];
   const T* bp[B_IT];
   auto set_ptrs = [&](int t) {
@@ -110,12 +103,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
     const int m0 = tm * BM_, n0 = tn * BN;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      int ar = m0 + (i * NW + wave) * RPP + srow; ar = ar < M ? ar : M - 1;   // edge rows are re-read, never stored
+      int ar = m0 + (i * NW + wave) * 8 + srow; ar = ar < M ? ar : M - 1;   // edge rows are re-read, never stored
       ap[i] = A + (size_t)ar * lda + scol;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      int br = n0 + (i * NW + wave) * RPP + srow; br = br < N ? br : N - 1;
+      int br = n0 + (i * NW + wave) * 8 + srow; br = br < N ? br : N - 1;
       bp[i] = Bt + (size_t)br * ldb + scol;
     }
   };
@@ -126,7 +119,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   // (MIXED is a template parameter: with the fp8 loop compiled into every instantiation the single-operand kernels carry
   // ~17 more VGPRs and the 256x256 residual epilogue spills: K = 3072, N = 768 went 267 -> 290 us)
   constexpr bool mixed = MIXED;
-  const int nkb = K / BK_, nk = mixed ? nkb + nkb / 2 : (g.a_split ? 2 * nkb : nkb);
+  const int nkb = K / BK, nk = mixed ? nkb + nkb / 2 : (g.a_split ? 2 * nkb : nkb);
   int lround = 0, lt = tile_of(0), lkt = 0, lslot = 0;
   if (lt >= ntiles) return;
   set_ptrs(lt);
@@ -134,8 +127,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
     if (lt >= ntiles) return false;
     char* base = smem + lslot * STAGE;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) glds16(ap[i] + lkt * BK_, base + (i * NW + wave) * 1024);
-    const int bk = ((lkt >= nkb && !mixed) ? lkt - nkb : lkt) * BK_;
+    for (int i = 0; i < A_IT; ++i) glds16(ap[i] + lkt * BK, base + (i * NW + wave) * 1024);
+    const int bk = ((lkt >= nkb && !mixed) ? lkt - nkb : lkt) * BK;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) glds16(bp[i] + bk, base + A_BYTES + (i * NW + wave) * 1024);
     if constexpr (CAN_FOLD) {
@@ -169,11 +162,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   // ---- fragment addressing ------------------------------------------------------------------------
   const int wm = wave / WCN, wn = wave % WCN;
   const int fr = lane & 15, fg = lane >> 4;
-  const int a_off = (wm * (WMF * 16) + fr) * ROWB;
-  const int b_off = A_BYTES + (wn * 64 + fr) * ROWB;
-  constexpr int FRB = 16 * ROWB;                      // bytes between consecutive 16-row fragments
-  const int c0 = BK_ == 64 ? ((0 + fg) ^ (fr & 7)) * 16 : (fg ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) * 16;        // k-step 0 chunk
-  const int c1 = ((4 + fg) ^ (fr & 7)) * 16;        // k-step 1 chunk (64-deep stages)
+  const int a_off = (wm * (WMF * 16) + fr) * 128;
+  const int b_off = A_BYTES + (wn * 64 + fr) * 128;
+  const int c0 = ((0 + fg) ^ (fr & 7)) * 16;        // k-step 0 chunk
+  const int c1 = ((4 + fg) ^ (fr & 7)) * 16;        // k-step 1 chunk
   // fp8 stage: the lane's 32 consecutive k-bytes (k = 32 fg .. 32 fg + 31) are source chunks 2 fg and 2 fg + 1
   [[maybe_unused]] const int e0 = ((2 * fg) ^ (fr & 7)) * 16, e1 = ((2 * fg + 1) ^ (fr & 7)) * 16;
   [[maybe_unused]] const int sc_w = 127 - g.w8_exp, sc_a = 127 - Lo8<T>::EXP;      // e8m0 scale bytes: undo the exponents of the two fp8 planes
@@ -249,18 +241,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
       // when the k-step changes) are issued BEFORE the 8 MFMAs of group s, so hipcc's counted lgkmcnt lets the LDS
       // latency run under the matrix pipe instead of in front of every 8-MFMA burst.  (-DMVLPT_FRAG_DEPTH=3, two groups
       // of lookahead, measured 5 % SLOWER on long-K shapes: 8192^3 1.23 vs 1.30 PF in the same run.)
-      constexpr int PAIRS = WMF / 2, GROUPS = (BK_ / 32) * PAIRS;
+      constexpr int PAIRS = WMF / 2, GROUPS = 2 * PAIRS;
       constexpr int DEPTH = MVLPT_FRAG_DEPTH;          // 2 = double-buffered (one group ahead), 3 = two groups ahead
       v8 bfr[2][4], afr[DEPTH][2];
       auto load_b = [&](int ks, v8 (&bf)[4]) {
         const int c = ks ? c1 : c0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = *(const v8*)(base + b_off + j * FRB + c);
+        for (int j = 0; j < 4; ++j) bf[j] = *(const v8*)(base + b_off + j * 2048 + c);
       };
       auto load_a2 = [&](int ks, int pair, v8 (&af)[2]) {
         const int c = ks ? c1 : c0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *(const v8*)(base + a_off + (pair * 2 + i) * FRB + c);
+        for (int i = 0; i < 2; ++i) af[i] = *(const v8*)(base + a_off + (pair * 2 + i) * 2048 + c);
       };
       load_b(0, bfr[0]);
 #pragma unroll
@@ -339,13 +331,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    // (a 32-KiB slot holds seven waves' scratch: the eighth wave's lies behind the LayerNorm-folding region)
-    char* const scratch = (NW * EPI_SCRATCH_PER_WAVE <= STAGE || wave < NW - 1) ? smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE
-                                                                                  : smem + NS * STAGE + XLDS_BYTES_WIDE;
 #pragma unroll
     for (int hh = 0; hh < WMF / 4; ++hh)
       epilogue_store<T, EPI>(g, acc[hh], tm * BM_ + wm * (WMF * 16) + hh * 64, tn * BN + wn * 64, lane,
-                             LinearRows<144>{scratch}, LinearRows<272>{scratch},
+                             LinearRows<144>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE},
+                             LinearRows<272>{smem + lslot * STAGE + wave * EPI_SCRATCH_PER_WAVE},
                              FoldCtx{xlds, xtab, wm * (WMF * 16) + hh * 64, wn, WCN, MIXED ? 2 : (g.ln_split ? 1 : 0)});
     MVLPT_TR(9);
     __builtin_amdgcn_s_barrier();
@@ -969,18 +959,17 @@ static hipError_t launch_pcp(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   return launch_pcp_m<T, EPI, false>(g, s, ea, eb);
 }
 
-template <typename T, int EPI, int BM_, int BN_, int NW, int NS, bool MIXED, int BK_ = BK>
+template <typename T, int EPI, int BM_, int BN_, int NW, int NS, bool MIXED>
 static hipError_t launch_geo_m(const GemmArgs& g, int wg_per_cu, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
-  constexpr int LDS = NS * (BM_ + BN_) * BK_ * 2;
-  constexpr int TAIL = BK_ == 32 ? EPI_SCRATCH_PER_WAVE : 0;      // 32-deep stages: the eighth wave's epilogue scratch (behind XLDS_BYTES_WIDE)
+  constexpr int LDS = NS * (BM_ + BN_) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED, BK_>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS + (LDS + XLDS_BYTES_WIDE <= 160 * 1024 ? XLDS_BYTES_WIDE : XLDS_BYTES) + TAIL);
+    (void)hipFuncSetAttribute((const void*)gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS + (LDS + XLDS_BYTES_WIDE <= 160 * 1024 ? XLDS_BYTES_WIDE : XLDS_BYTES));
     attr_set = true;
   }
   // LayerNorm folding: 16 KiB behind the ring (the consumer's row partials / the producer's per-tile column-block sums)
-  const int lds = BK_ == 32 ? LDS + XLDS_BYTES_WIDE + TAIL : LDS + (epi_folds(EPI) ? xlds_bytes(g.fold_ntp) : (EPI == EPI_RESID32_LN ? XLDS_BYTES : 0));
+  const int lds = LDS + (epi_folds(EPI) ? xlds_bytes(g.fold_ntp) : (EPI == EPI_RESID32_LN ? XLDS_BYTES : 0));
   if (lds > 160 * 1024) return hipErrorInvalidValue;      // (launch_one keeps 8-slot consumers off the 3-deep 256x128 ring)
 
   int cus = stream_cus(s);
@@ -992,7 +981,7 @@ static hipError_t launch_geo_m(const GemmArgs& g, int wg_per_cu, hipStream_t s, 
   // experiment: at most MVLPT_GEMM_MAXTILES tiles per workgroup (a CU is handed back to the dispatcher that often); 0 = persistent
   static const int maxtiles = getenv("MVLPT_GEMM_MAXTILES") ? atoi(getenv("MVLPT_GEMM_MAXTILES")) : 0;
   if (maxtiles > 0 && (tiles + maxtiles - 1) / maxtiles > resident) resident = (tiles + maxtiles - 1) / maxtiles;
-  hipExtLaunchKernelGGL((gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED, BK_>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), lds, s,
+  hipExtLaunchKernelGGL((gemm_bt_kernel<T, EPI, BM_, BN_, NW, NS, MIXED>), dim3(tiles < resident ? tiles : resident), dim3(NW * 64), lds, s,
                         ea, eb, 0, g);
   return hipGetLastError();
 }
@@ -1055,10 +1044,6 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   }
   if (geo >= 2 && big) {
     *tile_m = 256; *tile_n = 256;
-    // experiment: 32-deep stages in a 4-deep ring (three stages in flight), single operands
-    static const int bk32 = getenv("MVLPT_GEMM_BK32") ? atoi(getenv("MVLPT_GEMM_BK32")) : 0;
-    if (bk32 && g.a_split == 0 && g.K / 32 >= 4 && !(epi_folds(EPI) && g.fold_ntp > 8))
-      return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo_m<T, EPI, 256, 256, 8, 4, false, 32>(g, 1, s, ea, eb);
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
   }
   // (a folded consumer with 8-slot rows needs 20 KiB behind its ring: the 3-deep 256x128 ring has 16 left -> 256x256 or 128x128)
