@@ -62,6 +62,12 @@ int mvlpt_set_precision(void* handle, int mode);
  * stand-alone LayerNorm pass over the residual stream disappears.  mode 0: off, 1: image tower, 2: both towers (default;
  * environment MVLPT_LN_FOLD); towers with fewer than `min_rows` token rows (default 4096) keep the stand-alone kernel. */
 int mvlpt_set_ln_fold(void* handle, int mode, int min_rows);
+/* Packed residual stream (on by default; environment MVLPT_RESID_PACKED): an fp16 image tower that has no prompt rows and keeps
+ * nothing for a backward (the CoOp configurations, BASELINE configs[0..1]; clip/model.py:185-188 `x = x + ...`) carries the
+ * residual stream as hi = round16(x) + one byte with the next 8 bits of x instead of fp32, and hi is at the same time the
+ * 16-bit operand of the GEMM behind every LayerNorm (its gamma folded into the frozen weight): 6 instead of 10 bytes of memory
+ * traffic per element and residual update, x carried to 2^-20.  0: the fp32 stream everywhere. */
+int mvlpt_set_resid_packed(void* handle, int on);
 /* `vpt_dropout` of the reference (trainers/mvlpt.py:165, 424 and :77): the visual prompt rows are expanded over the batch and THEN
  * dropped out, so every image has its own mask.  masks = fp32 [n_layers, B, n_vpt, width] on the device, 0 or 1 / (1 - p): layer 0
  * belongs to the shallow prompts, layer l >= 1 to the deep prompts spliced in front of block l.  The NEXT mvlpt_image_fwd multiplies
@@ -183,6 +189,18 @@ int mvlpt_op_gemm_ln_producer(int dtype, const void* A, int a_split, const void*
 int mvlpt_op_gemm_folded(int dtype, int epi, const void* A16, int a_split, const void* Bt, int ldb, int w8_exp, int M, int N, int K,
                          const float* colsum, const float* bias2, const float* part, int ntp, int nt, void* out, void* out2,
                          mvlpt_stream_t stream);
+/* ---- packed residual stream at kernel level (see mvlpt_set_resid_packed; fp16 only).  An element x is stored as hi = round16(x)
+ * and lo = clamp((bits(x) - bits(float(hi))) >> 5, -128, 127) (int8): x' = bits(float(hi)) + (lo << 5).
+ * fold_weight: Wg = round16(W16 * gamma) [N, ldg], colsum = row sums of Wg (load time).  respk_pack: fp32 rows -> (hi, lo) and,
+ *   when part != NULL, {sum, sum of squares} of each row in slot 0 of its ntp slots (the others 0).  respk_unpack: rows r * row_mul
+ *   of (hi, lo) -> fp32.  gemm_residp: (hi_out, lo_out) = pack(A Bt^T + bias + unpack(hi_in, lo_in)) (in place allowed) and the
+ *   row statistics of the fp32 value as in gemm_ln_producer; the consumer is gemm_folded on A16 = hi_out with Bt = Wg. */
+int mvlpt_op_fold_weight(const void* W16, int ld, const float* gamma, void* Wg16, int ldg, float* colsum, int N, int K,
+                         mvlpt_stream_t stream);
+int mvlpt_op_respk_pack(const float* x, void* hi, uint8_t* lo, float* part, int ntp, int rows, int d, mvlpt_stream_t stream);
+int mvlpt_op_respk_unpack(const void* hi, const uint8_t* lo, int row_mul, float* out, int rows, int d, mvlpt_stream_t stream);
+int mvlpt_op_gemm_residp(const void* A, const void* Bt, int ldb, int M, int N, int K, const float* bias, const void* hi_in,
+                         const uint8_t* lo_in, void* hi_out, uint8_t* lo_out, float* part, int ntp, int* nt, mvlpt_stream_t stream);
 int mvlpt_op_layernorm_fwd_mixed(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,
                                  mvlpt_stream_t stream);
 int mvlpt_op_layernorm_bwd_mixed(int dtype, const void* dy, const float* x, const float* gamma, const float* resid, float* out32,

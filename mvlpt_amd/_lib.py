@@ -48,6 +48,7 @@ SIGNATURES = {
     "mvlpt_set_precision": (_i, [_vp, _i]),
     "mvlpt_trim": (_i, [_vp]),
     "mvlpt_set_ln_fold": (_i, [_vp, _i, _i]),
+    "mvlpt_set_resid_packed": (_i, [_vp, _i]),
     "mvlpt_set_vpt_dropout": (_i, [_vp, _vp, _i]),
     "mvlpt_last_error": (C.c_char_p, [_vp]),
     "mvlpt_version": (C.c_char_p, []),
@@ -75,6 +76,10 @@ SIGNATURES = {
     "mvlpt_op_fold_vectors": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mvlpt_op_gemm_ln_producer": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, C.POINTER(C.c_int), _vp]),
     "mvlpt_op_gemm_folded": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "mvlpt_op_fold_weight": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "mvlpt_op_respk_pack": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mvlpt_op_respk_unpack": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),
+    "mvlpt_op_gemm_residp": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_int), _vp]),
     "mvlpt_op_layernorm_fwd_mixed": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mvlpt_op_layernorm_bwd_mixed": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mvlpt_op_attention32_fwd_mixed": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -99,6 +99,38 @@ __device__ __forceinline__ float join_lo8(T hi, uint32_t lo8_word, int byte) {
   return to_f32<T>(hi) + l * (1.0f / (float)(1 << Lo8<T>::EXP));
 }
 
+// Packed residual stream (fp16 towers without a gradient): a fp32 value x travels as hi = round16(x) — which is at
+// the same time the 16-bit A operand of the GEMM behind the next LayerNorm — plus ONE byte that carries the next 8 bits of x:
+// for a normal fp16 `hi`, float(hi) has 13 zero mantissa bits and the fp32 bit patterns differ by d = bits(x) - bits(float(hi)),
+// |d| <= 2^12 (integer arithmetic on the bit patterns handles the mantissa / exponent carries and both signs);
+// lo = clamp(d >> 5, -128, 127) as int8 and x' = bits(float(hi)) + (lo << 5) is x to 2^-9 of an fp16 ulp (~2^-20 relative; fp16
+// subnormals: to 2^-25 absolute).  6 bytes per element and residual update (3 read + 3 written) instead of 10
+// (fp32 read + fp32 written + the 16-bit operand copy).
+__device__ __forceinline__ uint32_t respk_split4(f32x4 v, f16x4& hi) {
+  int q[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float x = v[e];
+    asm volatile("" : "+v"(x));      // (see split16: one rounding of the materialised value)
+    hi[e] = (f16)x;
+    const int d = __builtin_bit_cast(int, x) - __builtin_bit_cast(int, (float)hi[e]);
+    const int t = d >> 5;
+    q[e] = t < -128 ? -128 : (t > 127 ? 127 : t);      // (v_med3_i32; only fp16 subnormals and round-to-even ties ever clamp)
+  }
+  // bytes 0 of q[0..3] -> one word (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first, 0x0c = 0)
+  const uint32_t a = __builtin_amdgcn_perm((uint32_t)q[1], (uint32_t)q[0], 0x0c0c0400u);
+  const uint32_t b = __builtin_amdgcn_perm((uint32_t)q[3], (uint32_t)q[2], 0x04000c0cu);
+  return a | b;
+}
+__device__ __forceinline__ f32x4 respk_join4(f16x4 hi, uint32_t lo) {
+  f32x4 r;
+  r[0] = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)hi[0]) + (__builtin_amdgcn_sbfe((int)lo, 0, 8) << 5));
+  r[1] = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)hi[1]) + (__builtin_amdgcn_sbfe((int)lo, 8, 8) << 5));
+  r[2] = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)hi[2]) + (__builtin_amdgcn_sbfe((int)lo, 16, 8) << 5));
+  r[3] = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)hi[3]) + (((int)lo >> 24) << 5));
+  return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -107,7 +107,10 @@ struct Linear {
   void* w = nullptr; void* wt = nullptr; float* b = nullptr; int out = 0, in = 0;
   int ldw = 0, ldwt = 0, e8 = 0;
   float *fold_s = nullptr, *fold_b = nullptr;   // LayerNorm folding: W gamma and b + W beta of the LayerNorm in front (qkv: ln_1, fc: ln_2)
+  // packed residual stream (fp16 image tower without a gradient): round16(W * gamma) [out, in] and its row sums
+  void* wg = nullptr; float* fold_sg = nullptr;
   WRef fw() const { return WRef{w, ldw, e8}; }      // forward Bt operand  [out, in]
+  WRef fwg() const { return WRef{wg, in, 0}; }
   WRef bw() const { return WRef{wt, ldwt, e8}; }    // dX Bt operand       [in, out]
 };
 struct LNp { float* g = nullptr; float* b = nullptr; };
@@ -147,6 +150,9 @@ struct Engine {
   int fold_mode = 2;    // LayerNorm folding: 0 off, 1 image tower, 2 both towers (MVLPT_LN_FOLD, mvlpt_set_ln_fold)
   int fold_min_rows = 4096;   // towers with fewer token rows keep the stand-alone LayerNorm (a handful of tiles: nothing to win)
   bool fold_ready = false;
+  // packed residual stream: the fp16 image tower without prompts and without a backward carries x as hi (fp16, at the
+  // same time the A operand behind every LayerNorm) + one byte instead of fp32 + a 16-bit copy.  MVLPT_RESID_PACKED / mvlpt_set_resid_packed
+  int resid_packed = 1;
   const float* vpt_mask = nullptr;   // mvlpt_set_vpt_dropout: [layers, B, n_vpt, d] masks of the visual prompt rows, or null
   int vpt_mask_layers = 0;
   bool lo8 = true;      // split towers of MVLPT_PREC_SPLIT_GRAD use the mixed pair (hi + e5m2 residual byte; MVLPT_SPLIT_LO8=0: 16-bit pairs)
@@ -208,6 +214,7 @@ struct ProfScope {
 struct Fold {
   const float* ln_gamma = nullptr; void* ln_x16 = nullptr; int ln_split = 0; float* ln_part = nullptr; int ln_ntp = 0;   // producer
   const float* fold_part = nullptr; const float* fold_colsum = nullptr; int fold_ntp = 0, fold_nt = 0;                   // consumer
+  const void* rp_hi_in = nullptr; const uint8_t* rp_lo_in = nullptr; uint8_t* rp_lo_out = nullptr;                       // packed stream (EPI_RESIDP_LN)
 };
 hipError_t gemm(Engine* E, int epi, const void* A, WRef Bt, int M, int N, int K, const float* bias, const void* aux,
                 const float* resid, void* out, void* out2, hipStream_t s, int dtype = -1, int a_split = 0, const Fold* f = nullptr,
@@ -217,10 +224,11 @@ hipError_t gemm(Engine* E, int epi, const void* A, WRef Bt, int M, int N, int K,
   if (f) {
     g.ln_gamma = f->ln_gamma; g.ln_x16 = f->ln_x16; g.ln_split = f->ln_split; g.ln_part = f->ln_part; g.ln_ntp = f->ln_ntp;
     g.fold_part = f->fold_part; g.fold_colsum = f->fold_colsum; g.fold_ntp = f->fold_ntp; g.fold_nt = f->fold_nt;
+    g.rp_hi_in = f->rp_hi_in; g.rp_lo_in = f->rp_lo_in; g.rp_lo_out = f->rp_lo_out;
   }
   g.out_lo8 = (a_split == 2 && (epi == EPI_GELU_SPLIT || epi == EPI_GELUBWD_SPLIT)) ? 1 : 0;
   const int dt = dtype >= 0 ? dtype : E->dt;
-  const double ob = (epi == EPI_RESID32) ? 8.0 : (epi == EPI_RESID32_LN) ? 8.0 + 2.0 * (a_split ? 1.5 : 1.0) : ((epi == EPI_STORE32 || epi == EPI_STORE_SPLIT) ? 4.0 : ((epi == EPI_GELUBWD || epi == EPI_GELU_SPLIT) ? 4.0 :
+  const double ob = (epi == EPI_RESIDP_LN) ? 6.0 : (epi == EPI_RESID32) ? 8.0 : (epi == EPI_RESID32_LN) ? 8.0 + 2.0 * (a_split ? 1.5 : 1.0) : ((epi == EPI_STORE32 || epi == EPI_STORE_SPLIT) ? 4.0 : ((epi == EPI_GELUBWD || epi == EPI_GELU_SPLIT) ? 4.0 :
                     (epi == EPI_GELUBWD_SPLIT ? 6.0 : 2.0)));
   // the dominant kernel is timed by its own dispatch (start/stop timestamps of the AQL packet): no marker packets
   hipEvent_t ea = nullptr, eb = nullptr;
@@ -421,6 +429,36 @@ int block_fwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s, 
   return 0;
 }
 
+// block_fwd on the PACKED residual stream (common.h respk_*, kernels.h EPI_RESIDP_LN): fp16 tower, single operands, nothing saved,
+// both LayerNorms folded.  The stream lives in st.x[0] as hi [T,d] fp16 | lo [T,d] bytes and is updated in place; the hi plane is
+// the A operand of the QKV / MLP-up GEMMs, whose weights carry the LayerNorm's gamma (Linear::wg).  part[0] holds the row
+// statistics of the stream on entry (the previous block's FC2, or the pack kernel in front of block 0).
+int block_fwd_packed(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
+  const Block& B = W.blocks[l];
+  const int T = st.N * st.L, d = st.d;
+  void* hi = st.x[0];
+  uint8_t* lo = (uint8_t*)st.x[0] + (size_t)T * d * 2;
+  Fold fq = fold_consumer(st, 0, B.qkv), fo, ff, fp;
+  fq.fold_colsum = B.qkv.fold_sg;
+  HIPCHK(E, gemm(E, EPI_STORE16, hi, B.qkv.fwg(), T, 3 * d, d, B.qkv.fold_b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, 0, &fq));
+  {
+    AttnArgs a{st.qkv[l], st.attn[l], nullptr, st.N, st.L, st.H, st.causal ? 1 : 0};
+    const double fl = 4.0 * st.L * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0);
+    ProfScope ps(E, s, PC_ATTN_FWD, fl, (double)T * d * 2.0 * 4.0);
+    HIPCHK(E, launch_attn_fwd(E->dt, a, s));
+  }
+  if (!fold_producer(E, st, 1, T, d, d, B.ln2, s, &fo)) return fail(E, MVLPT_ERR_STATE, "packed residual stream: out-projection cannot produce the ln_2 statistics");
+  fo.rp_hi_in = hi; fo.rp_lo_in = lo; fo.rp_lo_out = lo;
+  HIPCHK(E, gemm(E, EPI_RESIDP_LN, st.attn[l], B.o.fw(), T, d, d, B.o.b, nullptr, nullptr, hi, nullptr, s, -1, 0, &fo));
+  ff = fold_consumer(st, 1, B.fc);
+  ff.fold_colsum = B.fc.fold_sg;
+  HIPCHK(E, gemm(E, EPI_GELU, hi, B.fc.fwg(), T, 4 * d, d, B.fc.fold_b, nullptr, nullptr, st.a16, nullptr, s, -1, 0, &ff));
+  if (!fold_producer(E, st, 0, T, d, 4 * d, B.ln1, s, &fp)) return fail(E, MVLPT_ERR_STATE, "packed residual stream: MLP down-projection cannot produce the ln_1 statistics");
+  fp.rp_hi_in = hi; fp.rp_lo_in = lo; fp.rp_lo_out = lo;
+  HIPCHK(E, gemm(E, EPI_RESIDP_LN, st.a16, B.pr.fw(), T, d, 4 * d, B.pr.b, nullptr, nullptr, hi, nullptr, s, -1, 0, &fp));
+  return 0;
+}
+
 // dX-only backward of one block: dx32/dx16 hold d(block output) on entry and d(block input) on exit
 int block_bwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
   if (st.exact) return block_bwd_x(E, W, st, l, s);
@@ -547,6 +585,15 @@ int prepare_fold(Engine* E, hipStream_t s) {
           L.fold_s = (float*)p; L.fold_b = (float*)p + L.out;
         }
         HIPCHK(E, launch_fold_vectors(E->dt, L.w, L.ldw, ln.g, ln.b, L.b, L.fold_s, L.fold_b, L.out, d, s));
+        if (W == &E->vis && E->dt == DT_F16 && E->resid_packed) {      // packed residual stream: gamma inside the weight
+          if (!L.wg) {
+            void* p = nullptr;
+            HIPCHK(E, hipMalloc(&p, (size_t)L.out * L.in * 2 + (size_t)L.out * sizeof(float)));
+            E->owned.push_back(p);
+            L.wg = p; L.fold_sg = (float*)((char*)p + (size_t)L.out * L.in * 2);
+          }
+          HIPCHK(E, launch_fold_weight(L.w, L.ldw, ln.g, L.wg, L.in, L.fold_sg, L.out, d, s));
+        }
       }
     }
   }
@@ -585,6 +632,7 @@ int mvlpt_create(const MvlptArch* a, void** handle) {
   E->arch = *a; E->dt = a->compute_dtype;
   if (const char* v = getenv("MVLPT_SPLIT_LO8")) E->lo8 = atoi(v) != 0;
   if (const char* v = getenv("MVLPT_LN_FOLD")) E->fold_mode = atoi(v);
+  if (const char* v = getenv("MVLPT_RESID_PACKED")) E->resid_packed = atoi(v) ? 1 : 0;
   if (const char* v = getenv("MVLPT_LN_FOLD_MIN_ROWS")) E->fold_min_rows = atoi(v) > 0 ? atoi(v) : 1;
   E->vis.width = a->vision_width; E->vis.layers = a->vision_layers; E->vis.heads = a->vision_heads;
   E->vis.blocks.resize(a->vision_layers);
@@ -636,6 +684,13 @@ int mvlpt_stream_destroy(mvlpt_stream_t stream) {
 
 int mvlpt_stream_cus(mvlpt_stream_t stream) { return stream_cus((hipStream_t)stream); }
 
+int mvlpt_set_resid_packed(void* h, int on) {
+  Engine* E = (Engine*)h;
+  if (!E) return MVLPT_ERR_ARG;
+  if ((on != 0) != (E->resid_packed != 0)) E->fold_ready = false;      // the gamma-folded weights are built by prepare_fold
+  E->resid_packed = on ? 1 : 0;
+  return 0;
+}
 int mvlpt_set_ln_fold(void* h, int mode, int min_rows) {
   Engine* E = (Engine*)h;
   if (!E) return MVLPT_ERR_ARG;
@@ -795,10 +850,22 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   { ProfScope ps(E, s, PC_GLUE, 0, (double)npatch * E->Kp * 6.0);
     HIPCHK(E, launch_patchify(E->dt, image, image_dtype, patches, B, A.image_resolution, A.patch_size, E->Kp, s)); }
   HIPCHK(E, gemm(E, EPI_STORE32, patches, WRef{E->conv_w, 0, 0}, (int)npatch, dv, E->Kp, nullptr, nullptr, nullptr, pe, nullptr, s));
+  // Packed residual stream (block_fwd_packed): fp16 tower, no prompts, nothing saved, every LayerNorm folded.  The fp32 token
+  // rows go to a16 first (free until the first MLP) and are packed into x[0] together with the row statistics of ln_1 of block 0.
+  const int nt_d = dv / 128, ntp_d = (nt_d + 1) & ~1;
+  const bool packed = E->resid_packed && E->dt == DT_F16 && !save && !exact && st.fold && n_vpt == 0 && dv % 128 == 0 &&
+                      ntp_d <= FOLD_NTP && E->vis.blocks[0].qkv.wg != nullptr;
+  void* const xhi = st.x[0];
+  uint8_t* const xlo = (uint8_t*)st.x[0] + (size_t)B * Lv * dv * 2;
   { ProfScope ps(E, s, PC_GLUE, 0, (double)B * Lv * dv * 8.0);
-    HIPCHK(E, launch_assemble_tokens(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, vpt, n_vpt, st.x[0], B, G2, dv, s, vmask(0))); }
+    HIPCHK(E, launch_assemble_tokens(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, vpt, n_vpt, packed ? (float*)st.a16 : st.x[0], B, G2, dv, s, vmask(0))); }
+  if (packed) {
+    ProfScope ps(E, s, PC_GLUE, 0, (double)B * Lv * dv * 7.0);
+    HIPCHK(E, launch_respk_pack_rows((const float*)st.a16, xhi, xlo, st.part[0], ntp_d, B * Lv, dv, s));
+    st.nt[0] = nt_d; st.ntp[0] = ntp_d;
+  }
   bool cls_only_last = false;
-  bool ln1_ready = false;       // LayerNorm folding: the previous block's FC2 left this block's ln_1 input in folded form
+  bool ln1_ready = packed;      // LayerNorm folding: the previous block's FC2 left this block's ln_1 input in folded form
   // ln_1 of block l can be folded when nothing touches the residual stream between FC2 of block l-1 and it: not behind a
   // deep-prompt overwrite, not behind a skipped block
   auto next_foldable = [&](int l) -> const LNp* {
@@ -822,6 +889,7 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
       }
     }
     if (l == E->vis.layers - 1) { cls_only_last = true; break; }
+    if (packed) { if (int rc = block_fwd_packed(E, E->vis, st, l, s)) return rc; continue; }
     bool produced = false;
     if (int rc = block_fwd(E, E->vis, st, l, s, ln1_ready, next_foldable(l), &produced)) return rc;
     ln1_ready = produced;
@@ -842,8 +910,9 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
     Fold fq;
     if (ln1_ready) fq = fold_consumer(st, 0, Bk.qkv);
     else HIPCHK(E, ln_fwd(E, E->dt, xin, nullptr, 1, Bk.ln1, st.h16, T, dv, s, xs));
-    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, st.h16, Bk.qkv.fw(), T, 3 * dv, dv, ln1_ready ? Bk.qkv.fold_b : Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs,
-                   ln1_ready ? &fq : nullptr));
+    if (packed) fq.fold_colsum = Bk.qkv.fold_sg;       // A = the stream's hi plane, gamma inside the weight
+    HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, packed ? xhi : st.h16, packed ? Bk.qkv.fwg() : Bk.qkv.fw(), T, 3 * dv, dv,
+                   ln1_ready ? Bk.qkv.fold_b : Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs, ln1_ready ? &fq : nullptr));
     if (xs) {
       // only the CLS rows of the attention output are produced: the backward (delta = rowsum(dO * O) over EVERY row, with
       // dO = 0 off the CLS rows) must not meet uninitialised memory there
@@ -856,7 +925,8 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
     }
     { ProfScope ps(E, s, PC_GLUE, 0, (double)B * dv * 12.0);
       HIPCHK(E, launch_copy_rows_strided(st.attn[l], E->ac16, B, (size_t)Lv * dv * 2 * X, (size_t)dv * 2 * X, (int)(dv * 2 * X), s));
-      HIPCHK(E, launch_copy_rows_strided(xin, E->xc32, B, (size_t)Lv * dv * 4, (size_t)dv * 4, dv * 4, s)); }
+      if (packed) HIPCHK(E, launch_respk_unpack_rows(xhi, xlo, Lv, E->xc32, B, dv, s));
+      else HIPCHK(E, launch_copy_rows_strided(xin, E->xc32, B, (size_t)Lv * dv * 4, (size_t)dv * 4, dv * 4, s)); }
     HIPCHK(E, gemm(E, EPI_RESID32, E->ac16, Bk.o.fw(), B, dv, dv, Bk.o.b, nullptr, E->xc32, xmid, nullptr, s, -1, xs));
     HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, Bk.ln2, E->hc16, B, dv, s, xs));
     HIPCHK(E, gemm(E, xs ? EPI_GELU_SPLIT : EPI_GELU, E->hc16, Bk.fc.fw(), B, 4 * dv, dv, Bk.fc.b, nullptr, nullptr, E->gc16, save ? E->uc16 : nullptr, s, -1, xs));
@@ -1218,6 +1288,30 @@ int mvlpt_op_gemm_folded(int dtype, int epi, const void* A16, int a_split, const
   g.out_lo8 = (a_split == 2 && epi == EPI_GELU_SPLIT) ? 1 : 0;
   g.fold_part = part; g.fold_colsum = colsum; g.fold_ntp = ntp; g.fold_nt = nt;
   OPCHK(launch_gemm(dtype, epi, g, (hipStream_t)stream));
+  return 0;
+}
+// ---- packed residual stream, kernel level (the same launches block_fwd_packed makes)
+int mvlpt_op_fold_weight(const void* W16, int ld, const float* gamma, void* Wg16, int ldg, float* colsum, int N, int K, mvlpt_stream_t stream) {
+  OPCHK(launch_fold_weight(W16, ld, gamma, Wg16, ldg, colsum, N, K, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_respk_pack(const float* x, void* hi, uint8_t* lo, float* part, int ntp, int rows, int d, mvlpt_stream_t stream) {
+  OPCHK(launch_respk_pack_rows(x, hi, lo, part, ntp, rows, d, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_respk_unpack(const void* hi, const uint8_t* lo, int row_mul, float* out, int rows, int d, mvlpt_stream_t stream) {
+  OPCHK(launch_respk_unpack_rows(hi, lo, row_mul, out, rows, d, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_gemm_residp(const void* A, const void* Bt, int ldb, int M, int N, int K, const float* bias, const void* hi_in,
+                         const uint8_t* lo_in, void* hi_out, uint8_t* lo_out, float* part, int ntp, int* nt, mvlpt_stream_t stream) {
+  GemmArgs g{A, Bt, M, N, K, bias, nullptr, nullptr, hi_out, nullptr};
+  g.ldb = ldb;
+  g.rp_hi_in = hi_in; g.rp_lo_in = lo_in; g.rp_lo_out = lo_out; g.ln_part = part; g.ln_ntp = ntp;
+  const int bn = gemm_tile_n(DT_F16, EPI_RESIDP_LN, g, (hipStream_t)stream);
+  if (bn <= 0 || N % bn || N / 128 > ntp) { g_create_err = "gemm_residp: ntp smaller than N / 128"; return MVLPT_ERR_ARG; }
+  if (nt) *nt = N / 128;
+  OPCHK(launch_gemm(DT_F16, EPI_RESIDP_LN, g, (hipStream_t)stream));
   return 0;
 }
 int mvlpt_op_cast_mixed(int dtype, const float* in, void* out, int64_t rows, int d, mvlpt_stream_t stream) {

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
                              FoldCtx{xlds, xtab, wm * (WMF * 16) + hh * 64, wn, WCN, MIXED ? 2 : (g.ln_split ? 1 : 0)});
     MVLPT_TR(9);
     __builtin_amdgcn_s_barrier();
-    if constexpr (EPI == EPI_RESID32_LN) {
+    if constexpr (epi_ln_producer(EPI)) {
       // the tile's row partials: one 8-byte slot per (row, 128 output columns) = the sum of two wave column blocks, whatever
       // the tile geometry — the statistics a row gets (and the order they are summed in) do not depend on the geometry the
       // launcher picks for the batch size (tests/test_hip_properties.py: a batch in two halves equals the whole bit for bit).
@@ -551,7 +551,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pc_kernel(GemmArgs g) {
   const int w4 = wave & 3;
   const int M = g.M, N = g.N, K = g.K;
   const int tilesN = N / BN;
-  const int t = blockIdx.x;
+  // XCD-aware order (as in the persistent kernels): workgroup b runs on XCD b % 8; each XCD takes a run of consecutive tiles
+  // (N-fastest), so the tiles that share an A panel share an L2.  In plain order the 4 column tiles of a panel (N = 512)
+  // sit on 4 different XCDs and every A panel crosses the fabric 4 times.
+  int t = blockIdx.x;
+  if (g.xcd_order) {
+    const int G = gridDim.x, gq = G >> 3, gr = G & 7, xcd = t & 7;
+    t = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (t >> 3);
+  }
   const int tm = t / tilesN, tn = t - tm * tilesN;
   const int m0 = tm * BM_, n0 = tn * BN;
   const int nkb = K / BK, nk = MIXED ? nkb + nkb / 2 : (g.a_split ? 2 * nkb : nkb);
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pc_kernel(GemmArgs g) {
       __builtin_amdgcn_s_barrier();
       if (f + NS - 1 < nk) issue(f + NS - 1);
     }
-    if constexpr (EPI == EPI_RESID32_LN) __builtin_amdgcn_s_barrier();
+    if constexpr (epi_ln_producer(EPI)) __builtin_amdgcn_s_barrier();
     return;
   }
 
@@ -673,7 +680,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pc_kernel(GemmArgs g) {
   char* const scr = smem + ((nk + 1) & (NS - 1)) * STAGE + w4 * EPI_SCRATCH_PER_WAVE;
   const FoldCtx fc{xlds, nullptr, wm * 64, wn, 2, MIXED ? 2 : (g.ln_split ? 1 : 0)};
   epilogue_store<T, EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, lane, LinearRows<144>{scr}, LinearRows<272>{scr}, fc);
-  if constexpr (EPI == EPI_RESID32_LN) {
+  if constexpr (epi_ln_producer(EPI)) {
     __builtin_amdgcn_s_barrier();
     if (tid < BM_) {
       const int row = m0 + tid;
@@ -694,7 +701,10 @@ static hipError_t launch_pc_m(const GemmArgs& g, hipStream_t s, hipEvent_t ea, h
     attr_set = true;
   }
   const int tiles = ((g.M + 127) / 128) * (g.N / 128);
-  hipExtLaunchKernelGGL((gemm_pc_kernel<T, EPI, MIXED>), dim3(tiles), dim3(512), LDS, s, ea, eb, 0, g);
+  static const int xcd_order = getenv("MVLPT_PC_XCD_ORDER") ? atoi(getenv("MVLPT_PC_XCD_ORDER")) : 1;
+  GemmArgs q = g;
+  q.xcd_order = xcd_order;
+  hipExtLaunchKernelGGL((gemm_pc_kernel<T, EPI, MIXED>), dim3(tiles), dim3(512), LDS, s, ea, eb, 0, q);
   return hipGetLastError();
 }
 template <typename T, int EPI>
@@ -925,7 +935,7 @@ __global__ __launch_bounds__(768, 1) void gemm_pcp_kernel(GemmArgs g) {
                            FoldCtx{xlds, xtab, wm * 64, wn, 2, MIXED ? 2 : (g.ln_split ? 1 : 0)});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (EPI == EPI_RESID32_LN) {
+    if constexpr (epi_ln_producer(EPI)) {
       if (tid < BM_) {
         const int row = tm * BM_ + tid;
         if (row < M) {
@@ -969,7 +979,7 @@ static hipError_t launch_geo_m(const GemmArgs& g, int wg_per_cu, hipStream_t s, 
     attr_set = true;
   }
   // LayerNorm folding: 16 KiB behind the ring (the consumer's row partials / the producer's per-tile column-block sums)
-  const int lds = LDS + (epi_folds(EPI) ? xlds_bytes(g.fold_ntp) : (EPI == EPI_RESID32_LN ? XLDS_BYTES : 0));
+  const int lds = LDS + (epi_folds(EPI) ? xlds_bytes(g.fold_ntp) : (epi_ln_producer(EPI) ? XLDS_BYTES : 0));
   if (lds > 160 * 1024) return hipErrorInvalidValue;      // (launch_one keeps 8-slot consumers off the 3-deep 256x128 ring)
 
   int cus = stream_cus(s);
@@ -1009,6 +1019,7 @@ static GemmArgs row_slice(const GemmArgs& g, int m_lo, int rows) {
   if (g.out2) r.out2 = (char*)g.out2 + on * 2;
   if (g.aux) r.aux = (const char*)g.aux + on * 2;
   if (g.resid) r.resid = g.resid + on;
+  if (g.rp_hi_in) { r.rp_hi_in = (const char*)g.rp_hi_in + on * 2; r.rp_lo_in = g.rp_lo_in + on; r.rp_lo_out = g.rp_lo_out + on; }
   return r;
 }
 
@@ -1037,7 +1048,7 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   const bool r15 = 2 * t128 >= 3 * cus;      // >= 1.5 rounds of 256x128 tiles
   // (the phased kernel has no fp8 stages: mixed pairs take the plain 256x128 geometry)
   // (nor the LayerNorm-folding fields: folded GEMMs take the plain geometries)
-  constexpr bool folded = epi_folds(EPI) || EPI == EPI_RESID32_LN;
+  constexpr bool folded = epi_folds(EPI) || epi_ln_producer(EPI);
   if (g.a_split != 2 && !folded && r15 && (phased == 1 || (phased == 2 && Keff >= 2048 && !big))) {
     *tile_m = 256; *tile_n = 128;
     if constexpr (!folded) return ea == (hipEvent_t)-1 ? hipSuccess : launch_phased<T, EPI>(g, s, ea, eb);
@@ -1133,6 +1144,9 @@ static hipError_t launch_epi(const GemmArgs& g, int epi, hipStream_t s, hipEvent
     case EPI_GELUBWD_SPLIT: return launch_t<T, EPI_GELUBWD_SPLIT>(g, s, ea, eb);
     case EPI_STORE_SPLIT: return launch_t<T, EPI_STORE_SPLIT>(g, s, ea, eb);
     case EPI_RESID32_LN: return launch_t<T, EPI_RESID32_LN>(g, s, ea, eb);
+    case EPI_RESIDP_LN:      // the packed stream is an fp16 format
+      if constexpr (__is_same(T, f16)) return launch_t<T, EPI_RESIDP_LN>(g, s, ea, eb);
+      else return hipErrorInvalidValue;
   }
   return hipErrorInvalidValue;
 }
@@ -1141,7 +1155,7 @@ template <typename T>
 static int tile_n_epi(const GemmArgs& g, int epi, hipStream_t s) {
   int bm = 0, bn = 0;
   switch (epi) {      // (the geometry does not depend on the epilogue except for the phased routing, which folded GEMMs skip)
-    case EPI_RESID32_LN: (void)launch_one<T, EPI_RESID32_LN>(g, s, (hipEvent_t)-1, nullptr, &bm, &bn); break;
+    case EPI_RESID32_LN: case EPI_RESIDP_LN: (void)launch_one<T, EPI_RESID32_LN>(g, s, (hipEvent_t)-1, nullptr, &bm, &bn); break;
     default: (void)launch_one<T, EPI_RESID32>(g, s, (hipEvent_t)-1, nullptr, &bm, &bn); break;
   }
   return bn;
@@ -1159,6 +1173,8 @@ hipError_t launch_gemm(int dtype, int epi, const GemmArgs& g, hipStream_t s, hip
   if (g.ldo && (g.ldo < 2 * g.N || (g.ldo % 8) != 0 || !(epi == EPI_GELU_SPLIT || epi == EPI_GELUBWD_SPLIT || epi == EPI_STORE_SPLIT))) return hipErrorInvalidValue;
   if ((epi == EPI_RESID32 || epi == EPI_RESID32_LN) && !g.resid) return hipErrorInvalidValue;
   if (epi == EPI_RESID32_LN && (!g.ln_gamma || !g.ln_x16 || !g.ln_part || g.ln_ntp <= 0 || (g.ln_ntp & 1))) return hipErrorInvalidValue;
+  if (epi == EPI_RESIDP_LN && (dtype != DT_F16 || g.a_split || !g.rp_hi_in || !g.rp_lo_in || !g.rp_lo_out || !g.ln_part || g.ln_ntp <= 0 || (g.ln_ntp & 1)))
+    return hipErrorInvalidValue;
   if (g.fold_part) {
     const bool can = epi == EPI_STORE16 || epi == EPI_GELU || epi == EPI_STORE_SPLIT || epi == EPI_GELU_SPLIT;
     const int nk = g.a_split == 2 ? g.K / BK + g.K / 128 : (g.a_split ? 2 : 1) * (g.K / BK);

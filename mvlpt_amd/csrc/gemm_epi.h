@@ -122,10 +122,10 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
   f32x4 bv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (fc.bias_lds && EPI != EPI_RESID32_LN && !fold) {
+  if (fc.bias_lds && !epi_ln_producer(EPI) && !fold) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) bv[j] = *(const __attribute__((address_space(3))) f32x4*)(fc.bias_lds + (fc.wn * 64 + j * 16 + fg * 4) * 4);
-  } else if (g.bias && EPI != EPI_RESID32_LN && !fold) {
+  } else if (g.bias && !epi_ln_producer(EPI) && !fold) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + nbase + j * 16 + fg * 4);
   }
@@ -209,6 +209,19 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
     // load while LDS-DMA is in flight, and that wait would also drain the stores issued before it.
     f32x4 rv[4][4];
     v4 uv[4][4];
+    [[maybe_unused]] uint32_t lw[4][4];      // packed stream: the hi plane arrives in uv, the byte plane here
+    if constexpr (EPI == EPI_RESIDP_LN) {
+#pragma unroll
+      for (int i = 2 * H0; i < 2 * H1; ++i)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          int m = mbase + i * 16 + it * 4 + rq;
+          m = m < M ? m : M - 1;
+          const size_t o = (size_t)m * N + nbase + c * 4;
+          uv[i][it] = __builtin_nontemporal_load((const v4*)((const T*)g.rp_hi_in + o));
+          lw[i][it] = __builtin_nontemporal_load((const uint32_t*)(g.rp_lo_in + o));
+        }
+    }
     if constexpr (RESID || EPI == EPI_GELUBWD || EPI == EPI_GELUBWD_SPLIT) {
 #pragma unroll
       for (int i = 2 * H0; i < 2 * H1; ++i)
@@ -226,11 +239,12 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
       if (g.bias) colb = *(const f32x4*)(g.bias + nbase + c * 4);
       cols = *(const f32x4*)(g.ln_gamma + nbase + c * 4);
     }
+    if constexpr (EPI == EPI_RESIDP_LN) { if (g.bias) colb = *(const f32x4*)(g.bias + nbase + c * 4); }
     if constexpr (fold) {      // the bias is added behind the row scale: the raw accumulators are staged
       colb = *(const f32x4*)(fc.tab + XLDS_BIAS + (fc.wn * 64 + c * 4) * 4);
       cols = *(const f32x4*)(fc.tab + XLDS_COLSUM + (fc.wn * 64 + c * 4) * 4);
     }
-    constexpr bool stage_raw = fold || EPI == EPI_RESID32_LN;
+    constexpr bool stage_raw = fold || epi_ln_producer(EPI);
 #pragma unroll
     for (int i = 2 * H0; i < 2 * H1; ++i) {
 #pragma unroll
@@ -262,6 +276,21 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
             store_a16<T>(g.ln_x16, fc.xs, (size_t)m, N, nbase + c * 4, v * cols);
           }
           __builtin_amdgcn_sched_barrier(0);     // one row segment at a time: interleaved passes cost registers this kernel does not have
+        } else if constexpr (EPI == EPI_RESIDP_LN) {
+          if constexpr (sizeof(T) == 2 && !__is_same(T, bf16)) {
+            v += respk_join4(uv[i][it], lw[i][it]) + colb;
+            float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+            float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            s1 = row16_sum(s1); s2 = row16_sum(s2);
+            if (c == 0) *(float2*)(fc.xl + ((size_t)(fc.mrel + i * 16 + r) * fc.wcn + fc.wn) * 8) = float2{s1, s2};
+            v4 hi;
+            const uint32_t lo = respk_split4(v, hi);
+            if (m < M) {
+              __builtin_nontemporal_store(hi, (v4*)((T*)g.out + o));
+              __builtin_nontemporal_store(lo, (uint32_t*)(g.rp_lo_out + o));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         } else if constexpr (EPI == EPI_GELUBWD) {
           v4 w;
 #pragma unroll

@@ -617,6 +617,73 @@ hipError_t launch_fold_vectors(int dtype, const void* W16, int ld, const float* 
   return hipGetLastError();
 }
 
+// Packed residual stream (common.h respk_*, kernels.h EPI_RESIDP_LN): the LayerNorm's gamma moves from the activation into the
+// consumer's weight, Wg[n,k] = round16(W[n,k] * gamma[k]) (the values the MFMA multiplies), colsum[n] = sum_k Wg[n,k] in fp32.
+// One wave per output column, fixed summation order.  Load time only.
+__global__ __launch_bounds__(256) void fold_weight_kernel(const f16* __restrict__ W, int ld, const float* __restrict__ gamma,
+                                                          f16* __restrict__ Wg, int ldg, float* __restrict__ colsum, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const f16* w = W + (size_t)n * ld;
+  f16* o = Wg + (size_t)n * ldg;
+  float sg = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const f16 v = (f16)((float)w[k] * gamma[k]);
+    o[k] = v;
+    sg += (float)v;
+  }
+  sg = wave_sum(sg);
+  if (lane == 0) colsum[n] = sg;
+}
+hipError_t launch_fold_weight(const void* W16, int ld, const float* gamma, void* Wg16, int ldg, float* colsum, int N, int K, hipStream_t s) {
+  if (N <= 0 || K <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fold_weight_kernel, dim3((N + 3) / 4), dim3(256), 0, s, (const f16*)W16, ld, gamma, (f16*)Wg16, ldg, colsum, N, K);
+  return hipGetLastError();
+}
+
+// fp32 rows -> packed stream (hi [rows,d] fp16 + lo [rows,d] bytes) and the LayerNorm-folding partials of the rows: slot 0 of
+// row r = {sum x, sum x^2} over the whole row, slots 1 .. ntp-1 = 0 (the consumer adds the slots in order).  One wave per row.
+__global__ __launch_bounds__(256) void respk_pack_rows_kernel(const float* __restrict__ x, f16* __restrict__ hi, uint8_t* __restrict__ lo,
+                                                              float* __restrict__ part, int ntp, int rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t o = (size_t)row * d;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)(x + o + c));
+    s1 += (v[0] + v[1]) + (v[2] + v[3]);
+    s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    f16x4 h;
+    const uint32_t l = respk_split4(v, h);
+    *(f16x4*)(hi + o + c) = h;
+    *(uint32_t*)(lo + o + c) = l;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (part && lane < ntp) *(float2*)(part + ((size_t)row * ntp + lane) * 2) = lane == 0 ? float2{s1, s2} : float2{0.f, 0.f};
+}
+hipError_t launch_respk_pack_rows(const float* x, void* hi, uint8_t* lo, float* part, int ntp, int rows, int d, hipStream_t s) {
+  if (rows <= 0 || d <= 0 || (d & 3) || ntp > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(respk_pack_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, (f16*)hi, lo, part, ntp, rows, d);
+  return hipGetLastError();
+}
+// out[r, :] = value of packed row r * row_mul  (fp32; the CLS rows in front of the last block / ln_post)
+__global__ __launch_bounds__(256) void respk_unpack_rows_kernel(const f16* __restrict__ hi, const uint8_t* __restrict__ lo, int row_mul,
+                                                                float* __restrict__ out, int rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t o = (size_t)row * row_mul * d;
+  for (int c = lane * 4; c < d; c += 256)
+    *(f32x4*)(out + (size_t)row * d + c) = respk_join4(*(const f16x4*)(hi + o + c), *(const uint32_t*)(lo + o + c));
+}
+hipError_t launch_respk_unpack_rows(const void* hi, const uint8_t* lo, int row_mul, float* out, int rows, int d, hipStream_t s) {
+  if (rows <= 0 || d <= 0 || (d & 3) || row_mul < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(respk_unpack_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, (const f16*)hi, lo, row_mul, out, rows, d);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ head (fp32)
 // xn = x / ||x||  (no epsilon: trainers/mvlpt.py:550-551)
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ xn,

@@ -27,12 +27,17 @@ enum GemmEpi {
   // internal: EPI_STORE16 / EPI_GELU / EPI_STORE_SPLIT / EPI_GELU_SPLIT with the consumer side of the folding compiled in
   // (launch_gemm selects them when GemmArgs::fold_part is set; callers pass the plain values)
   EPI_STORE16_FOLD = 9, EPI_GELU_FOLD = 10, EPI_STORE_SPLIT_FOLD = 11, EPI_GELU_SPLIT_FOLD = 12,
+  // EPI_RESID32_LN on the PACKED residual stream (fp16, single operands; GemmArgs::rp_*): the stream is read and written as
+  // hi (16-bit, [M,N]) + lo (one byte, [M,N]) — common.h respk_* — and the hi plane IS the consumer's A operand (the LayerNorm's
+  // gamma is folded into the consumer's weight instead of into the activation): no fp32 stream, no separate 16-bit copy
+  EPI_RESIDP_LN = 13,
 };
 constexpr int epi_base(int epi) {
   return epi == EPI_STORE16_FOLD ? EPI_STORE16 : epi == EPI_GELU_FOLD ? EPI_GELU : epi == EPI_STORE_SPLIT_FOLD ? EPI_STORE_SPLIT
          : epi == EPI_GELU_SPLIT_FOLD ? EPI_GELU_SPLIT : epi;
 }
 constexpr bool epi_folds(int epi) { return epi >= EPI_STORE16_FOLD && epi <= EPI_GELU_SPLIT_FOLD; }
+constexpr bool epi_ln_producer(int epi) { return epi == EPI_RESID32_LN || epi == EPI_RESIDP_LN; }
 struct GemmArgs {
   const void* A;       // [M,K] 16-bit
   const void* Bt;      // [N,K] 16-bit
@@ -62,6 +67,7 @@ struct GemmArgs {
   // channels (M = 7 700, K = 2048 pair rows of 8 KiB: 56 vs 36 us next to K = 1920 / 2176, profiles/r04_pitch_probe.txt): the engine
   // pads such rows by 128 bytes.
   int lda = 0, ldo = 0;
+  int xcd_order = 0;   // set by the one-tile-per-workgroup launcher (gemm_pc_kernel): XCD-aware tile order
   // ---- LayerNorm folding: LN(x) W^T = rstd_r * ((x * gamma) W^T)[r,n] - rstd_r * mean_r * (W gamma)[n] + (W beta)[n], so the
   // GEMM in front of a LayerNorm hands the un-normalised row to the GEMM behind it and the LayerNorm pass (one read of the fp32
   // residual stream + one 16-bit write per LayerNorm) disappears.  No atomics, no extra launch: every output tile owns its slots.
@@ -81,6 +87,12 @@ struct GemmArgs {
   const float* fold_part = nullptr;
   const float* fold_colsum = nullptr;
   int fold_ntp = 0, fold_nt = 0;
+  // ---- packed residual stream (EPI_RESIDP_LN): the stream in front of the GEMM is rp_hi_in [M,N] fp16 + rp_lo_in [M,N] bytes,
+  // the updated stream goes to `out` [M,N] fp16 (hi) + rp_lo_out [M,N] bytes; ln_part / ln_ntp as for EPI_RESID32_LN (the
+  // statistics are those of the fp32 value before it is packed).  In place (in == out) is allowed: a tile reads what it rewrites.
+  const void* rp_hi_in = nullptr;
+  const uint8_t* rp_lo_in = nullptr;
+  uint8_t* rp_lo_out = nullptr;
 #ifdef MVLPT_GEMM_TRACE
   long long* trace = nullptr;   // debug builds only: per-wave (point id << 56 | s_memtime) records of workgroup 0
 #endif
@@ -230,6 +242,13 @@ hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);
 // LayerNorm folding: colsum[n] = sum_k W16[n,k] gamma[k], bias2[n] = b[n] + sum_k W16[n,k] beta[k]  (W16 [N, ld] packed weight)
 hipError_t launch_fold_vectors(int dtype, const void* W16, int ld, const float* gamma, const float* beta, const float* b,
                                float* colsum, float* bias2, int N, int K, hipStream_t s);
+
+// packed residual stream (common.h respk_*, EPI_RESIDP_LN; fp16 only): gamma folded into the consumer's weight
+// (Wg = round16(W16 * gamma), colsum = its row sums), fp32 rows -> packed rows (+ LayerNorm-folding partials in slot 0 of ntp,
+// or part = null), packed rows r * row_mul -> fp32 rows
+hipError_t launch_fold_weight(const void* W16, int ld, const float* gamma, void* Wg16, int ldg, float* colsum, int N, int K, hipStream_t s);
+hipError_t launch_respk_pack_rows(const float* x, void* hi, uint8_t* lo, float* part, int ntp, int rows, int d, hipStream_t s);
+hipError_t launch_respk_unpack_rows(const void* hi, const uint8_t* lo, int row_mul, float* out, int rows, int d, hipStream_t s);
 
 // ---------------------------------------------------------------- head: cosine logits + cross-entropy (fp32)
 hipError_t launch_normalize_rows(const float* x, float* xn, float* norm, int rows, int d, hipStream_t s);

@@ -125,6 +125,10 @@ class Engine:
         """LayerNorm folding (include/mvlpt_hip.h: mvlpt_set_ln_fold): 0 off, 1 image tower, 2 both towers."""
         _lib.check(lib.mvlpt_set_ln_fold(self.h, int(mode), int(min_rows)), self.h, "set_ln_fold")
 
+    def set_resid_packed(self, on: bool) -> None:
+        """Packed residual stream of the prompt-free, gradient-free fp16 image tower (include/mvlpt_hip.h: mvlpt_set_resid_packed)."""
+        _lib.check(lib.mvlpt_set_resid_packed(self.h, int(bool(on))), self.h, "set_resid_packed")
+
     @_on_device
     def trim(self) -> None:
         """Release workspace blocks that were outgrown (epoch boundary: synchronises the device)."""
@@ -532,6 +536,46 @@ def op_gemm_ln_producer(A, Bt, bias, resid, gamma, a_split=0, x16_split=0, ldb=0
                                              _ptr(resid), _ptr(gamma), x16_split, _ptr(out), _ptr(x16), _ptr(part), ntp, C.byref(nt),
                                              _stream()), None, "op_gemm_ln_producer")
     return out, x16, part, nt.value
+
+
+# ---- packed residual stream at kernel level (include/mvlpt_hip.h: mvlpt_op_fold_weight / respk_pack / respk_unpack / gemm_residp)
+def op_fold_weight(W16: torch.Tensor, K: int, gamma):
+    """W16 fp16 [N, ld >= K] -> (Wg = round16(W16 * gamma) [N, K], colsum = row sums of Wg, fp32 [N])."""
+    N, ld = W16.shape
+    Wg = torch.empty(N, K, device=W16.device, dtype=torch.float16)
+    cs = torch.empty(N, device=W16.device, dtype=torch.float32)
+    _lib.check(lib.mvlpt_op_fold_weight(_ptr(W16), ld, _ptr(gamma), _ptr(Wg), K, _ptr(cs), N, K, _stream()), None, "op_fold_weight")
+    return Wg, cs
+
+
+def op_respk_pack(x: torch.Tensor, ntp: int = 0):
+    """fp32 [rows, d] -> (hi fp16 [rows, d], lo int8 [rows, d], part [rows, ntp, 2] or None)."""
+    rows, d = x.shape
+    hi = torch.empty(rows, d, device=x.device, dtype=torch.float16)
+    lo = torch.empty(rows, d, device=x.device, dtype=torch.int8)
+    part = torch.full((rows, ntp, 2), float("nan"), device=x.device, dtype=torch.float32) if ntp else None
+    _lib.check(lib.mvlpt_op_respk_pack(_ptr(x.contiguous()), _ptr(hi), _ptr(lo), _ptr(part), ntp, rows, d, _stream()), None, "op_respk_pack")
+    return hi, lo, part
+
+
+def op_respk_unpack(hi: torch.Tensor, lo: torch.Tensor, row_mul: int = 1):
+    rows, d = hi.shape[0] // row_mul, hi.shape[1]
+    out = torch.empty(rows, d, device=hi.device, dtype=torch.float32)
+    _lib.check(lib.mvlpt_op_respk_unpack(_ptr(hi), _ptr(lo), row_mul, _ptr(out), rows, d, _stream()), None, "op_respk_unpack")
+    return out
+
+
+def op_gemm_residp(A, Bt, bias, hi, lo, ldb=0, ntp=8, in_place=False):
+    """(hi', lo') = pack(A Bt^T + bias + unpack(hi, lo)); -> (hi', lo', part [M, ntp, 2], nt)."""
+    M, K = A.shape
+    N = Bt.shape[0]
+    ho = hi if in_place else torch.empty_like(hi)
+    lo_o = lo if in_place else torch.empty_like(lo)
+    part = torch.zeros(M, ntp, 2, device=A.device, dtype=torch.float32)
+    nt = C.c_int(0)
+    _lib.check(lib.mvlpt_op_gemm_residp(_ptr(A.contiguous()), _ptr(Bt), ldb, M, N, K, _ptr(bias), _ptr(hi), _ptr(lo), _ptr(ho), _ptr(lo_o),
+                                        _ptr(part), ntp, C.byref(nt), _stream()), None, "op_gemm_residp")
+    return ho, lo_o, part, nt.value
 
 
 def op_gemm_folded(x16, Bt, colsum, bias2, part, nt, epi=_lib.EPI_STORE16, a_split=0, ldb=0, w8_exp=0, out2=False):
