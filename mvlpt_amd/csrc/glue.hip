@@ -629,7 +629,9 @@ __global__ __launch_bounds__(256) void fold_weight_kernel(const f16* __restrict_
   f16* o = Wg + (size_t)n * ldg;
   float sg = 0.f;
   for (int k = lane; k < K; k += 64) {
-    const f16 v = (f16)((float)w[k] * gamma[k]);
+    float x = (float)w[k] * gamma[k];
+    asm volatile("" : "+v"(x));      // the fp32 product, then ONE conversion (not v_fma_mixlo_f16's single rounding of the exact product)
+    const f16 v = (f16)x;
     o[k] = v;
     sg += (float)v;
   }
