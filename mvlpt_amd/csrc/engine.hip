@@ -850,19 +850,20 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   { ProfScope ps(E, s, PC_GLUE, 0, (double)npatch * E->Kp * 6.0);
     HIPCHK(E, launch_patchify(E->dt, image, image_dtype, patches, B, A.image_resolution, A.patch_size, E->Kp, s)); }
   HIPCHK(E, gemm(E, EPI_STORE32, patches, WRef{E->conv_w, 0, 0}, (int)npatch, dv, E->Kp, nullptr, nullptr, nullptr, pe, nullptr, s));
-  // Packed residual stream (block_fwd_packed): fp16 tower, no prompts, nothing saved, every LayerNorm folded.  The fp32 token
-  // rows go to a16 first (free until the first MLP) and are packed into x[0] together with the row statistics of ln_1 of block 0.
+  // Packed residual stream (block_fwd_packed): fp16 tower, no prompts, nothing saved, every LayerNorm folded.  assemble_tokens
+  // writes the rows in the packed format together with the row statistics of ln_1 of block 0.
   const int nt_d = dv / 128, ntp_d = (nt_d + 1) & ~1;
   const bool packed = E->resid_packed && E->dt == DT_F16 && !save && !exact && st.fold && n_vpt == 0 && dv % 128 == 0 &&
                       ntp_d <= FOLD_NTP && E->vis.blocks[0].qkv.wg != nullptr;
   void* const xhi = st.x[0];
   uint8_t* const xlo = (uint8_t*)st.x[0] + (size_t)B * Lv * dv * 2;
-  { ProfScope ps(E, s, PC_GLUE, 0, (double)B * Lv * dv * 8.0);
-    HIPCHK(E, launch_assemble_tokens(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, vpt, n_vpt, packed ? (float*)st.a16 : st.x[0], B, G2, dv, s, vmask(0))); }
   if (packed) {
     ProfScope ps(E, s, PC_GLUE, 0, (double)B * Lv * dv * 7.0);
-    HIPCHK(E, launch_respk_pack_rows((const float*)st.a16, xhi, xlo, st.part[0], ntp_d, B * Lv, dv, s));
+    HIPCHK(E, launch_assemble_tokens_packed(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, xhi, xlo, st.part[0], ntp_d, B, G2, dv, s));
     st.nt[0] = nt_d; st.ntp[0] = ntp_d;
+  } else {
+    ProfScope ps(E, s, PC_GLUE, 0, (double)B * Lv * dv * 8.0);
+    HIPCHK(E, launch_assemble_tokens(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, vpt, n_vpt, st.x[0], B, G2, dv, s, vmask(0)));
   }
   bool cls_only_last = false;
   bool ln1_ready = packed;      // LayerNorm folding: the previous block's FC2 left this block's ln_1 input in folded form

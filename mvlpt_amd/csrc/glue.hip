@@ -260,12 +260,15 @@ hipError_t launch_patchify(int dtype, const void* image, int image_dtype, void* 
 // (no positional embedding, no ln_pre: trainers/mvlpt.py:57-62, 416-437); others: ln_pre(patch + pos[1+i]).
 // Grid-stride: resident waves walk the rows, the next row's patch-embedding loads are in flight while the current
 // row is normalised; gamma/beta stay in registers; streamed fp32 operands use non-temporal loads/stores.
-template <int NV>
+// PK: the rows go out in the packed residual-stream format (common.h respk_*: x = the hi plane [rows, d] fp16, xlo the byte plane)
+// together with the LayerNorm-folding statistics of block 0's ln_1 ({sum, sum of squares} in slot 0 of the row's ntp slots);
+// prompt-free towers only.
+template <int NV, bool PK>
 __global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
                                                               const float* __restrict__ pos, const float* __restrict__ g,
                                                               const float* __restrict__ bt, const float* __restrict__ vpt,
                                                               const float* __restrict__ vmask, int n_vpt, float* __restrict__ x, int B,
-                                                              int G2, int d) {
+                                                              int G2, int d, uint8_t* __restrict__ xlo, float* __restrict__ part, int ntp) {
   const int lane = threadIdx.x & 63;
   const int L = 1 + n_vpt + G2;
   const size_t rows = (size_t)B * L, nw = (size_t)gridDim.x * 4;
@@ -317,12 +320,25 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __res
         for (int e = 0; e < 4; ++e) { const float t = cur[k][e] - mean; q += t * t; }
       }
       const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+      [[maybe_unused]] float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int k = 0; k < NV; ++k) if (ok[k]) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (cur[k][e] - mean) * rstd * gg[k][e] + bb[k][e];
-        __builtin_nontemporal_store(o, (f32x4*)(xo + (k * 64 + lane) * 4));
+        if constexpr (PK) {
+          s1 += (o[0] + o[1]) + (o[2] + o[3]);
+          s2 += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+          f16x4 h;
+          const uint32_t l = respk_split4(o, h);
+          const size_t oo = row * d + (k * 64 + lane) * 4;
+          *(f16x4*)((f16*)x + oo) = h;
+          *(uint32_t*)(xlo + oo) = l;
+        } else __builtin_nontemporal_store(o, (f32x4*)(xo + (k * 64 + lane) * 4));
+      }
+      if constexpr (PK) {
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane < ntp) *(float2*)(part + (row * ntp + lane) * 2) = lane == 0 ? float2{s1, s2} : float2{0.f, 0.f};
       }
     }
 #pragma unroll
@@ -336,7 +352,22 @@ hipError_t launch_assemble_tokens(const float* patch_emb, const float* cls, cons
   const size_t want = (rows + 3) / 4;
   const dim3 grid((unsigned)(want < 2048 ? want : 2048)), block(256);
   const int nv = (d + 255) / 256;
-#define MVLPT_ASM_TOK(NV) hipLaunchKernelGGL(assemble_tokens_kernel<NV>, grid, block, 0, s, patch_emb, cls, pos, g, b, vpt, vmask, n_vpt, x, B, G2, d)
+#define MVLPT_ASM_TOK(NV) hipLaunchKernelGGL((assemble_tokens_kernel<NV, false>), grid, block, 0, s, patch_emb, cls, pos, g, b, vpt, vmask, n_vpt, x, B, G2, d, nullptr, nullptr, 0)
+  if (nv <= 2) MVLPT_ASM_TOK(2);
+  else if (nv == 3) MVLPT_ASM_TOK(3);
+  else if (nv == 4) MVLPT_ASM_TOK(4);
+  else MVLPT_ASM_TOK(8);
+#undef MVLPT_ASM_TOK
+  return hipGetLastError();
+}
+hipError_t launch_assemble_tokens_packed(const float* patch_emb, const float* cls, const float* pos, const float* g, const float* b,
+                                         void* hi, uint8_t* lo, float* part, int ntp, int B, int G2, int d, hipStream_t s) {
+  if (d % 4 || d > 2048 || ntp < 1 || ntp > 64) return hipErrorInvalidValue;
+  const size_t rows = (size_t)B * (1 + G2);
+  const size_t want = (rows + 3) / 4;
+  const dim3 grid((unsigned)(want < 2048 ? want : 2048)), block(256);
+  const int nv = (d + 255) / 256;
+#define MVLPT_ASM_TOK(NV) hipLaunchKernelGGL((assemble_tokens_kernel<NV, true>), grid, block, 0, s, patch_emb, cls, pos, g, b, nullptr, nullptr, 0, (float*)hi, B, G2, d, lo, part, ntp)
   if (nv <= 2) MVLPT_ASM_TOK(2);
   else if (nv == 3) MVLPT_ASM_TOK(3);
   else if (nv == 4) MVLPT_ASM_TOK(4);

@@ -219,6 +219,10 @@ hipError_t launch_patchify(int dtype, const void* image, int image_dtype, void* 
 hipError_t launch_assemble_tokens(const float* patch_emb, const float* cls, const float* pos, const float* g, const float* b,
                                   const float* vpt, int n_vpt, float* x, int B, int G2, int d, hipStream_t s,
                                   const float* vmask = nullptr /* [B, n_vpt, d] dropout mask of the prompt rows, or null */);
+// the same rows (no prompts) straight into the packed residual stream (hi [B*(1+G2), d] fp16, lo bytes) + the rows' {sum, sum of
+// squares} in slot 0 of `part` [rows][ntp][2]
+hipError_t launch_assemble_tokens_packed(const float* patch_emb, const float* cls, const float* pos, const float* g, const float* b,
+                                         void* hi, uint8_t* lo, float* part, int ntp, int B, int G2, int d, hipStream_t s);
 // x[b, 1+j, :] = rows[j, :]   (deep prompt overwrite, trainers/mvlpt.py:78-82)
 hipError_t launch_overwrite_rows(const float* rows, int n, float* x, int B, int L, int d, hipStream_t s, const float* vmask = nullptr);
 // prompts (forward_coop + positional embedding, trainers/mvlpt.py:439-515, 107/112)
