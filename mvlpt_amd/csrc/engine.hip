@@ -148,7 +148,7 @@ struct Engine {
   int dt = DT_F16;
   int prec_mode = MVLPT_PREC_SPLIT_GRAD;
   int fold_mode = 2;    // LayerNorm folding: 0 off, 1 image tower, 2 both towers (MVLPT_LN_FOLD, mvlpt_set_ln_fold)
-  int fold_min_rows = 4096;   // towers with fewer token rows keep the stand-alone LayerNorm (a handful of tiles: nothing to win)
+  int fold_min_rows = 4096;   // towers with fewer token rows keep the stand-alone LayerNorm (a handful of tiles: little to win — 2 % at 1 600 rows — and the small-tile consumer geometries are the least exercised: NOTES, round 5)
   bool fold_ready = false;
   // packed residual stream: the fp16 image tower without prompts and without a backward carries x as hi (fp16, at the
   // same time the A operand behind every LayerNorm) + one byte instead of fp32 + a 16-bit copy.  MVLPT_RESID_PACKED / mvlpt_set_resid_packed

@@ -134,3 +134,98 @@ def test_full_step_at_batch_256_is_bit_stable_with_both_towers_concurrent(method
         assert torch.equal(l, l0) and torch.equal(s, s0), f"logits / loss changed (repetition {k})"
         for n in g0:
             assert torch.equal(g[n], g0[n]), f"{n} changed (repetition {k})"
+
+
+@pytest.mark.parametrize("image_batch", [8, 12])
+def test_small_split_image_tower_with_folding_forced_on_is_bit_stable_under_a_concurrent_text_tower(image_batch):
+    """Round 5: with the LayerNorm folding forced on for a split image tower of 8 .. 16 images, the folded MLP-up consumer on mixed
+    pairs took the 128x128 geometry, whose output is timing-dependent while another stream runs the text tower (reproducer:
+    tools/fold_consumer_repro.py with MVLPT_DBG_FOLD128=1).  The launcher routes those problems to the 256x256 kernel; this is the
+    tower-level guard for that routing (40 % of the iterations differed before it)."""
+    from mvlpt_amd.class_prompts import load_class_prompts
+    from mvlpt_amd.config import get_cfg_default
+    from mvlpt_amd.model import CustomCLIP, FrozenCLIP
+    from mvlpt_amd.weights import ARCHS, make_state_dict
+    arch = ARCHS["ViT-B/16"]
+    cfg = get_cfg_default()
+    cfg.TRAINER.MVLPT.COOP.N_CTX = 16
+    pre, C = load_class_prompts("caltech101", 16)
+    torch.manual_seed(0)
+    model = CustomCLIP(cfg, ["c"] * C, FrozenCLIP(make_state_dict(arch, 3), "fp16", precision="split_grad"), pretokenized=pre).cuda()
+    pl, eng = model.prompt_learner, model.engine
+    ctx = pl.ctx.detach()
+    n, dv = 8, arch.vision_width
+    vpt = torch.randn(n, dv, device="cuda") * 0.05
+    deep = torch.randn(arch.vision_layers - 1, n, dv, device="cuda") * 0.05
+    x = torch.randn(image_batch, 3, 224, 224, device="cuda").half()
+    dfeat = torch.randn(image_batch, arch.embed_dim, device="cuda") * 1e-3
+
+    def image():
+        f = eng.image_fwd(x, vpt, deep, save_for_bwd=True).clone()
+        a, b = eng.image_bwd(dfeat)
+        return f, a.clone(), b.clone()
+
+    side = torch.cuda.Stream()
+    eng.set_ln_fold(2, 1)
+    try:
+        with torch.no_grad():
+            f0, a0, b0 = image()
+            torch.cuda.synchronize()
+            for it in range(25):
+                with torch.cuda.stream(side):
+                    eng.text_fwd(pl.token_prefix, pl.token_suffix, ctx, pl.layout, pl.eot, save_for_bwd=False)
+                f, a, b = image()
+                torch.cuda.synchronize()
+                assert torch.equal(f, f0), f"image features changed under a concurrent text tower (iteration {it})"
+                assert torch.equal(a, a0) and torch.equal(b, b0), f"visual-prompt gradients changed (iteration {it})"
+    finally:
+        eng.set_ln_fold(2, 4096)
+
+
+def test_folded_mlp_up_consumer_on_mixed_pairs_is_bit_stable_under_a_concurrent_text_tower():
+    """Kernel level (mvlpt_op_gemm_folded, epilogue 5 on mixed pairs, 2 460 x 3072 x 768: 480 tiles at 128x128): every launch equals
+    the first one while the text tower runs on another stream."""
+    from mvlpt_amd import engine as E
+    from mvlpt_amd.class_prompts import load_class_prompts
+    from mvlpt_amd.config import get_cfg_default
+    from mvlpt_amd.model import CustomCLIP, FrozenCLIP
+    from mvlpt_amd.weights import ARCHS, make_state_dict
+    L_ = E._lib
+    M, N1, K1, N2 = 2460, 768, 768, 3072
+    dev = "cuda"
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(M, K1, generator=g)
+    W1 = (torch.randn(N1, K1, generator=g) * K1 ** -0.5).half().float()
+    b1 = torch.randn(N1, generator=g) * 0.1
+    resid = torch.randn(M, N1, generator=g) * 2
+    gamma = 1 + 0.2 * torch.randn(N1, generator=g)
+    beta = 0.1 * torch.randn(N1, generator=g)
+    W2 = (torch.randn(N2, N1, generator=g) * N1 ** -0.5).half().float()
+    b2 = torch.randn(N2, generator=g) * 0.1
+    A2 = E.op_cast_mixed(A.to(dev), torch.float16)
+    W1p, e1 = E.op_pack_weight_mixed(W1.to(dev), torch.float16)
+    W2p, e2 = E.op_pack_weight_mixed(W2.to(dev), torch.float16)
+    out32, x16, part, nt = E.op_gemm_ln_producer(A2, W1p, b1.to(dev), resid.to(dev), gamma.to(dev), a_split=2, x16_split=2, ldb=W1p.shape[1], w8_exp=e1)
+    cs, bias2 = E.op_fold_vectors(W2p[:, :N1].contiguous(), N1, gamma.to(dev), beta.to(dev), b2.to(dev))
+
+    def run():
+        return E.op_gemm_folded(x16, W2p, cs, bias2, part, nt, epi=L_.EPI_GELU_SPLIT, a_split=2, ldb=W2p.shape[1], w8_exp=e2, out2=True)
+
+    arch = ARCHS["ViT-B/16"]
+    cfg = get_cfg_default()
+    cfg.TRAINER.MVLPT.COOP.N_CTX = 16
+    pre, C = load_class_prompts("caltech101", 16)
+    model = CustomCLIP(cfg, ["c"] * C, FrozenCLIP(make_state_dict(arch, 3), "fp16", precision="split_grad"), pretokenized=pre).cuda()
+    pl, eng = model.prompt_learner, model.engine
+    ctx = pl.ctx.detach()
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        ref = [t.clone() for t in run()]
+        torch.cuda.synchronize()
+        for it in range(30):
+            with torch.cuda.stream(side):
+                eng.text_fwd(pl.token_prefix, pl.token_suffix, ctx, pl.layout, pl.eot, save_for_bwd=False)
+            outs = [[t.clone() for t in run()] for _ in range(6)]
+            torch.cuda.synchronize()
+            for o in outs:
+                assert all(torch.equal(a, b) for a, b in zip(o, ref)), f"folded consumer output changed under concurrency (iteration {it})"
