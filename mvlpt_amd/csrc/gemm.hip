@@ -1046,7 +1046,6 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   const bool one_round = one_round_on && g.N % 256 == 0 && t256 <= cus && 100 * t256 >= one_round_pct * cus;
   const bool big = g.N % 256 == 0 && (t256 >= 4 * cus || (t256 >= 2 * cus && Keff >= 2048) || one_round);
   const bool r15 = 2 * t128 >= 3 * cus;      // >= 1.5 rounds of 256x128 tiles
-  auto t_fold_small = [&]() { return !r15; };   // ... fewer: the launcher would fall through to the 128x128 geometry
   // (the phased kernel has no fp8 stages: mixed pairs take the plain 256x128 geometry)
   // (nor the LayerNorm-folding fields: folded GEMMs take the plain geometries)
   constexpr bool folded = epi_folds(EPI) || epi_ln_producer(EPI);
@@ -1057,18 +1056,6 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   if (geo >= 2 && big) {
     *tile_m = 256; *tile_n = 256;
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
-  }
-  // The folded MLP-up consumer on mixed pairs (EPI_GELU_SPLIT_FOLD, a_split == 2) never takes the 128x128 / two-workgroups-per-CU
-  // geometry: at 257 .. 512 tiles (split image towers of 8 .. 16 images) its output is timing-dependent while another stream runs
-  // the text tower — a few rows, lanes 48-63 of a row segment, one fp32 component, off by up to 0.2 in ~40 % of the launches
-  // (tools/fold_consumer_repro.py, NOTES round 5; cause not found: not the GELU, not the byte conversion, not co-residency).  The
-  // 256x256 kernel computes the same shapes bit-stably (0 / 360), so small problems take it however under-filled.
-  if constexpr (epi_folds(EPI) && epi_base(EPI) == EPI_GELU_SPLIT) {
-    static const int allow128 = getenv("MVLPT_DBG_FOLD128") ? atoi(getenv("MVLPT_DBG_FOLD128")) : 0;      // the reproducer's switch
-    if (!allow128 && g.a_split == 2 && g.N % 256 == 0 && !big && t_fold_small()) {
-      *tile_m = 256; *tile_n = 256;
-      return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
-    }
   }
   // (a folded consumer with 8-slot rows needs 20 KiB behind its ring: the 3-deep 256x128 ring has 16 left -> 256x256 or 128x128)
   const bool wide_fold = epi_folds(EPI) && g.fold_ntp > 6;

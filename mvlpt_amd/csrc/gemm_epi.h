@@ -75,6 +75,24 @@ __device__ __forceinline__ void fold_build_coef(const GemmArgs& g, char* xl, cha
   cc = -a * mean;
   *(float2*)(tab + XLDS_COEF + row_rel * 8) = float2{a, cc};
 }
+// The consumer side of the folding on one register quad: rstd_r * acc + (-rstd_r * mean_r * colsum + bias2), element by element on
+// the SCALAR fma.  Left to itself hipcc packs the four elements into two v_pk_fma_f32 with op_sel (the row coefficients broadcast
+// into both halves of the pair); in gemm_bt_kernel<f16, EPI_GELU_SPLIT_FOLD, 128, 128, 4, 2, MIXED> that form delivered — only while
+// another stream's kernels shared the SIMDs, in ~40 % of the launches — a wrong LOW element in lanes 48-63 of a few row segments
+// (tools/fold_consumer_repro.py; the same code on scalar fmas: 0 of 360 launches; NOTES round 5).  v_pk_fma_f32 is not faster than
+// two v_fma_f32 on gfx950, so nothing is lost.  (Bit-identical results: both forms are fused.)
+__device__ __forceinline__ f32x4 fold_apply(float fa, float fcc, const f32x4& acc, const f32x4& colsum, const f32x4& bias2) {
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float t = fmaf(fcc, colsum[e], bias2[e]);
+    asm volatile("" : "+v"(t));
+    float w = fmaf(fa, acc[e], t);
+    asm volatile("" : "+v"(w));
+    r[e] = w;
+  }
+  return r;
+}
 // sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: quad butterflies, then the two mirrors.
 // VALU only (ds_bpermute-based shuffles would put ~8 LDS round trips into every row segment of the epilogue)
 __device__ __forceinline__ float row16_sum(float v) {
@@ -155,7 +173,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
           for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const f32x4 v = fa[ii] * acc[half * 2 + ii][j] + (fcc[ii] * sj[j] + bj[j]);
+              const f32x4 v = fold_apply(fa[ii], fcc[ii], acc[half * 2 + ii][j], sj[j], bj[j]);
               v4 w;
 #pragma unroll
               for (int e = 0; e < 4; ++e) w[e] = from_f32<T>((EPI == EPI_GELU && which == 0) ? quick_gelu(v[e]) : v[e]);
@@ -259,7 +277,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
         if constexpr (fold) {
           float fa, fcc;
           fold_row_coef(g, fc.tab, fc.mrel + i * 16 + r, fa, fcc);
-          v = fa * v + (fcc * cols + colb);
+          v = fold_apply(fa, fcc, v, cols, colb);
         }
         if constexpr (EPI == EPI_RESID32) {
           v += rv[i][it];

@@ -139,9 +139,9 @@ def test_full_step_at_batch_256_is_bit_stable_with_both_towers_concurrent(method
 @pytest.mark.parametrize("image_batch", [8, 12])
 def test_small_split_image_tower_with_folding_forced_on_is_bit_stable_under_a_concurrent_text_tower(image_batch):
     """Round 5: with the LayerNorm folding forced on for a split image tower of 8 .. 16 images, the folded MLP-up consumer on mixed
-    pairs took the 128x128 geometry, whose output is timing-dependent while another stream runs the text tower (reproducer:
-    tools/fold_consumer_repro.py with MVLPT_DBG_FOLD128=1).  The launcher routes those problems to the 256x256 kernel; this is the
-    tower-level guard for that routing (40 % of the iterations differed before it)."""
+    pairs takes the 128x128 geometry, whose output was timing-dependent while another stream ran the text tower (2 .. 19 of 40
+    iterations differed) as long as hipcc compiled the fold arithmetic to v_pk_fma_f32 with op_sel.  gemm_epi.h fold_apply keeps it on
+    scalar fmas; this is the tower-level guard (kernel level: the next test and tools/fold_consumer_repro.py)."""
     from mvlpt_amd.class_prompts import load_class_prompts
     from mvlpt_amd.config import get_cfg_default
     from mvlpt_amd.model import CustomCLIP, FrozenCLIP

@@ -180,7 +180,7 @@ def _clip(arch_name):
 
 @pytest.mark.parametrize("arch_name,B", [("ViT-B/16", 24), ("ViT-B/32", 96), ("ViT-L/14", 20)])
 def test_image_features_packed_vs_fp32_stream_vs_oracle(arch_name, B):
-    """B * L >= 4096 token rows: the towers fold their LayerNorms by default and the packed stream is what runs."""
+    """B * L >= 4096 token rows: the towers fold their LayerNorms by default; the packed stream is switched on for the first two runs."""
     from mvlpt_amd.weights import ARCHS
     from oracle import clip_oracle as O
     clip, sd = _clip(arch_name)
@@ -195,7 +195,7 @@ def test_image_features_packed_vs_fp32_stream_vs_oracle(arch_name, B):
         eng.set_resid_packed(False)
         f_plain = eng.image_fwd(image.cuda().half()).float().cpu()
     finally:
-        eng.set_resid_packed(True)
+        eng.set_resid_packed(False)
     assert torch.equal(f_packed, f_again)
     nref = min(B, 6)
     torch.set_num_threads(8)
@@ -226,4 +226,4 @@ def test_coop_fixtures_with_the_packed_tower(arch_name, name, packed):
         _check_inference(case, _inference_logits(case, build_model(case, clip, res, pre, suf), image), name)
     finally:
         clip.engine.set_ln_fold(2, 4096)
-        clip.engine.set_resid_packed(True)
+        clip.engine.set_resid_packed(False)

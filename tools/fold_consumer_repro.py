@@ -1,7 +1,8 @@
-"""Kernel-level reproducer of the timing-dependent output of the folded MLP-up consumer on mixed pairs at the 128x128 geometry
-(gemm_bt_kernel<f16, EPI_GELU_SPLIT_FOLD, 128, 128, 4 waves, 2-deep ring, MIXED>): the launcher routes around that geometry; MVLPT_DBG_FOLD128=1
-puts it back.  Usage (GPU box): [MVLPT_DBG_FOLD128=1] [NOFOLD=1] python tools/fold_consumer_repro.py M N2 mixed(0/1) gelu|store save_u(0/1) concurrent(0/1)
-e.g. MVLPT_DBG_FOLD128=1 python tools/fold_consumer_repro.py 2460 3072 1 gelu 1 1  -> ~40 % of the launches differ from the first one."""
+"""Kernel-level reproducer of a timing-dependent result (round 5): the folded MLP-up consumer on mixed pairs at the 128x128 geometry
+(gemm_bt_kernel<f16, EPI_GELU_SPLIT_FOLD, 128, 128, 4 waves, 2-deep ring, MIXED>), 2 460 x 3072 x 768, repeated while another stream runs the
+text tower: with the fold arithmetic compiled to v_pk_fma_f32 + op_sel ~40 % of the launches differed from the first one (lanes 48-63 of a row
+segment, the LOW element of a packed pair); on scalar fmas (gemm_epi.h fold_apply) 0 of 360.  Kept as the stress test for that class of bug.
+Usage (GPU box): [NOFOLD=1] python tools/fold_consumer_repro.py M N2 mixed(0/1) gelu|store save_u(0/1) concurrent(0/1)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
