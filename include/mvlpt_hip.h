@@ -66,9 +66,9 @@ int mvlpt_set_ln_fold(void* handle, int mode, int min_rows);
  * nothing for a backward (the CoOp configurations, BASELINE configs[0..1]; clip/model.py:185-188 `x = x + ...`) carries the
  * residual stream as hi = round16(x) + one byte with the next 8 bits of x instead of fp32, and hi is at the same time the
  * 16-bit operand of the GEMM behind every LayerNorm (its gamma folded into the frozen weight): 6 instead of 10 bytes of memory
- * traffic per element and residual update, x carried to 2^-20; image tower alone -1.7 %.  Parity-green and bit-stable by itself; updated in place it
- * returned ONE image's features 1e-3 off in ~1 of 1 000 - 3 000 towers while the text tower ran on another stream, with two alternating
- * sets of planes (what it does now) 0 of 12 000 (the fp32 stream: 0 of 19 200) — not the default until it has the same record.  0: the fp32 stream everywhere. */
+ * traffic per element and residual update, x carried to 2^-20; image tower alone -1.7 %.  Parity-green and bit-stable by itself, but with the
+ * text tower running on another stream ~1 tower in 1 000 - 6 000 returns ONE image's features 1e-3 off (cause not found; the fp32 stream:
+ * 0 in 59 200) — hence not the default.  0: the fp32 stream everywhere. */
 int mvlpt_set_resid_packed(void* handle, int on);
 /* `vpt_dropout` of the reference (trainers/mvlpt.py:165, 424 and :77): the visual prompt rows are expanded over the batch and THEN
  * dropped out, so every image has its own mask.  masks = fp32 [n_layers, B, n_vpt, width] on the device, 0 or 1 / (1 - p): layer 0

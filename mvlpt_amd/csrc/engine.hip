@@ -430,7 +430,7 @@ int block_fwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s, 
 }
 
 // block_fwd on the PACKED residual stream (common.h respk_*, kernels.h EPI_RESIDP_LN): fp16 tower, single operands, nothing saved,
-// both LayerNorms folded.  The stream lives in st.x[0] as hi [T,d] fp16 | lo [T,d] bytes (+ a second set, below); the hi plane is
+// both LayerNorms folded.  The stream lives in st.x[0] as hi [T,d] fp16 | lo [T,d] bytes and is updated in place; the hi plane is
 // the A operand of the QKV / MLP-up GEMMs, whose weights carry the LayerNorm's gamma (Linear::wg).  part[0] holds the row
 // statistics of the stream on entry (the previous block's FC2, or the pack kernel in front of block 0).
 int block_fwd_packed(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s) {
@@ -438,13 +438,6 @@ int block_fwd_packed(Engine* E, const TowerW& W, TowerState& st, int l, hipStrea
   const int T = st.N * st.L, d = st.d;
   void* hi = st.x[0];
   uint8_t* lo = (uint8_t*)st.x[0] + (size_t)T * d * 2;
-  // Two sets of planes: the out-projection reads the first and writes the second, the MLP down-projection the other way round (hi2 =
-  // h16, unused by this path; lo2 = the last quarter of x[0]).  Updated IN PLACE (MVLPT_RESID_PINGPONG=0) one image in ~1 000 - 3 000
-  // towers came out 1e-3 off while the text tower ran on another stream (a plane rewritten three kernels after a GEMM read it as its
-  // operand from any XCD's L2); with two sets: 0 of 12 000 (NOTES round 5).
-  static const int pingpong = getenv("MVLPT_RESID_PINGPONG") ? atoi(getenv("MVLPT_RESID_PINGPONG")) : 1;
-  void* hi2 = pingpong ? st.h16 : hi;
-  uint8_t* lo2 = pingpong ? (uint8_t*)st.x[0] + (size_t)T * d * 3 : lo;
   Fold fq = fold_consumer(st, 0, B.qkv), fo, ff, fp;
   fq.fold_colsum = B.qkv.fold_sg;
   HIPCHK(E, gemm(E, EPI_STORE16, hi, B.qkv.fwg(), T, 3 * d, d, B.qkv.fold_b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, 0, &fq));
@@ -455,13 +448,13 @@ int block_fwd_packed(Engine* E, const TowerW& W, TowerState& st, int l, hipStrea
     HIPCHK(E, launch_attn_fwd(E->dt, a, s));
   }
   if (!fold_producer(E, st, 1, T, d, d, B.ln2, s, &fo)) return fail(E, MVLPT_ERR_STATE, "packed residual stream: out-projection cannot produce the ln_2 statistics");
-  fo.rp_hi_in = hi; fo.rp_lo_in = lo; fo.rp_lo_out = lo2;
-  HIPCHK(E, gemm(E, EPI_RESIDP_LN, st.attn[l], B.o.fw(), T, d, d, B.o.b, nullptr, nullptr, hi2, nullptr, s, -1, 0, &fo));
+  fo.rp_hi_in = hi; fo.rp_lo_in = lo; fo.rp_lo_out = lo;
+  HIPCHK(E, gemm(E, EPI_RESIDP_LN, st.attn[l], B.o.fw(), T, d, d, B.o.b, nullptr, nullptr, hi, nullptr, s, -1, 0, &fo));
   ff = fold_consumer(st, 1, B.fc);
   ff.fold_colsum = B.fc.fold_sg;
-  HIPCHK(E, gemm(E, EPI_GELU, hi2, B.fc.fwg(), T, 4 * d, d, B.fc.fold_b, nullptr, nullptr, st.a16, nullptr, s, -1, 0, &ff));
+  HIPCHK(E, gemm(E, EPI_GELU, hi, B.fc.fwg(), T, 4 * d, d, B.fc.fold_b, nullptr, nullptr, st.a16, nullptr, s, -1, 0, &ff));
   if (!fold_producer(E, st, 0, T, d, 4 * d, B.ln1, s, &fp)) return fail(E, MVLPT_ERR_STATE, "packed residual stream: MLP down-projection cannot produce the ln_1 statistics");
-  fp.rp_hi_in = hi2; fp.rp_lo_in = lo2; fp.rp_lo_out = lo;
+  fp.rp_hi_in = hi; fp.rp_lo_in = lo; fp.rp_lo_out = lo;
   HIPCHK(E, gemm(E, EPI_RESIDP_LN, st.a16, B.pr.fw(), T, d, 4 * d, B.pr.b, nullptr, nullptr, hi, nullptr, s, -1, 0, &fp));
   return 0;
 }
