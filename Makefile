@@ -10,6 +10,14 @@ LIB   := mvlpt_amd/libmvlpt_hip.so
 
 ORACLE_SO := oracle/_build/libresample_oracle.so
 
+# Identity of the binary (mvlpt_version()): sha256 over the sources it is compiled from, and the git commit when there is one.
+# bench.py compares it with the hash recorded in profiles/gemm_hbm_traffic*.json and drops a traffic figure taken on another binary.
+HDRS     := $(sort $(wildcard $(CSRC)/*.h) include/mvlpt_hip.h)
+SRC_HASH := $(shell cat $(sort $(SRCS)) $(HDRS) | sha256sum | cut -c1-12)
+GIT_HASH := $(shell git rev-parse --short=12 HEAD 2>/dev/null || echo nogit)
+STAMP    := $(OBJDIR)/version.stamp
+$(shell mkdir -p $(OBJDIR); echo "$(SRC_HASH) $(GIT_HASH)" | cmp -s - $(STAMP) || echo "$(SRC_HASH) $(GIT_HASH)" > $(STAMP))
+
 all: $(LIB) $(ORACLE_SO)
 
 # CPU oracle of the input pipeline (test infrastructure only: never linked into $(LIB))
@@ -17,7 +25,11 @@ $(ORACLE_SO): oracle/resample_oracle.c
 	@mkdir -p oracle/_build
 	gcc -O2 -ffp-contract=off -shared -fPIC -o $@ $< -lm
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/attn_common.h $(CSRC)/gemm_epi.h include/mvlpt_hip.h
+$(OBJDIR)/engine.o: $(CSRC)/engine.hip $(HDRS) $(STAMP)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(FLAGS) -DMVLPT_SRC_HASH='"$(SRC_HASH)"' -DMVLPT_GIT_HASH='"$(GIT_HASH)"' -c $< -o $@
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 

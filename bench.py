@@ -192,6 +192,9 @@ SECONDARY_CONFIGS = [
 ]
 
 
+SECONDARY_BUDGET_S = 300
+
+
 def run_secondary_configs(dtype):
     import subprocess
     out = []
@@ -201,8 +204,14 @@ def run_secondary_configs(dtype):
                "--no-trim-extra", "--no-secondary"] + flags
         t0 = time.perf_counter()
         entry = {"workload": workload, "flags": " ".join(flags)}
+        # bounded: the three children together never add more than SECONDARY_BUDGET_S to the driver's run (a cold box needs ~10 s each)
+        left = SECONDARY_BUDGET_S - (t0 - t_all)
+        if left < 30:
+            entry["skipped"] = f"the {SECONDARY_BUDGET_S} s budget of the secondary passes is used up"
+            out.append(entry)
+            continue
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(200, left), cwd=ROOT)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or len(lines) != 1:
                 entry["error"] = (r.stderr or r.stdout)[-400:]
@@ -212,7 +221,7 @@ def run_secondary_configs(dtype):
                               "step_mfma_fraction": j["step_mfma_fraction"], "algorithmic_gflop_per_image": j["algorithmic_gflop_per_image"],
                               "per_gpu_batch": j["config"]["per_gpu_batch"], "child_workload": j["config"]["workload"]})
         except subprocess.TimeoutExpired:
-            entry["error"] = "timed out after 240 s"
+            entry["error"] = "timed out"
         entry["wall_s"] = round(time.perf_counter() - t0, 1)
         out.append(entry)
     return out, round(time.perf_counter() - t_all, 1)
@@ -423,6 +432,35 @@ def main():
     loss = float(out["loss"])
     assert loss == loss, "loss is NaN"
 
+    from mvlpt_amd import _lib as _L
+    import re as _re
+    lib_version = _L.lib.mvlpt_version().decode()
+    lib_src_hash = (_re.search(r"src:(\w+)", lib_version) or [None, None])[1]
+    # N > 1: who took part.  Every rank reports its device; the line shows N distinct devices on the RCCL backend without anyone
+    # reading logs, and the flat gradient all-reduce timed by itself (events, 20 calls after the timed region).
+    ranks_info, allreduce_us = None, None
+    shared_gpu_debug = os.environ.get("MVLPT_DEBUG_SHARE_GPU", "0") == "1"
+    if world > 1:
+        prop = torch.cuda.get_device_properties(local)
+        mine = {"rank": rank, "local_device": local, "device_name": prop.name, "device_uuid": str(getattr(prop, "uuid", "")),
+                "pci_bus_id": getattr(prop, "pci_bus_id", None), "backend": torch.distributed.get_backend(), "pid": os.getpid(),
+                "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
+        ranks_info = [None] * world
+        torch.distributed.all_gather_object(ranks_info, mine)
+        flats = [f.flat for f in getattr(trainer, "_flat_grads", {}).values() if f.flat.numel()]
+        if flats and not shared_gpu_debug:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            scratch = flats[0].clone()
+            for _ in range(3):
+                torch.distributed.all_reduce(scratch, op=torch.distributed.ReduceOp.AVG)
+            fence()
+            e0.record()
+            for _ in range(20):
+                torch.distributed.all_reduce(scratch, op=torch.distributed.ReduceOp.AVG)
+            e1.record()
+            torch.cuda.synchronize()
+            allreduce_us = {"value": round(e0.elapsed_time(e1) * 1e3 / 20, 1), "bytes": int(scratch.numel() * scratch.element_size()),
+                            "calls": 20, "note": "the step's one collective (flat fp32 prompt-gradient buffer, in-place AVG), back to back, event-timed on rank 0"}
     if rank == 0:
         B_global = args.batch * world
         ips = B_global * K / elapsed
@@ -450,7 +488,18 @@ def main():
                        "text_tower": "class-sharded over ranks" if (args.shard_text and world > 1) else "replicated per GPU", "loss": round(loss, 5)},
             "step_mfma_fraction": round(ips / world * gf_img / (MFMA_PEAK_TFLOPS * 1e3), 4),
             "algorithmic_gflop_per_image": round(gf_img, 3),
+            "library": lib_version,
         }
+        if ranks_info is not None:
+            ids = {(r.get("device_uuid") or "", str(r.get("pci_bus_id")), r["local_device"]) for r in ranks_info}
+            line["config"]["ranks"] = ranks_info
+            line["config"]["distinct_devices"] = len(ids)
+            if shared_gpu_debug:
+                line["config"]["debug_shared_gpu"] = "MVLPT_DEBUG_SHARE_GPU=1: every rank on cuda:0, collectives through gloo (a test mode, not a measurement)"
+            else:
+                assert len(ids) == world, f"{world} ranks but {len(ids)} distinct devices: {ranks_info}"
+                assert all(r["backend"] == "nccl" for r in ranks_info), "N > 1 must run on RCCL (backend nccl)"
+            line["allreduce_us"] = allreduce_us
         clock = mark.get("clock")
         if clock:
             line["clock"] = clock
@@ -461,9 +510,15 @@ def main():
         cfg_key = {("vpt", "ViT-B/16", 1000): "cfg3", ("upt", "ViT-B/16", 2191): "cfg4", ("upt", "ViT-L/14@336px", 1151): "cfg5"}.get(
             (args.method, args.arch, args.classes))
         tfile = TRAFFIC_FILE if is_headline else (TRAFFIC_FILE.replace(".json", f"_{cfg_key}.json") if cfg_key and not args.cut else None)
+        traffic_note = None
         if tfile and os.path.isfile(tfile):
             with open(tfile) as f:
-                traffic = json.load(f)       # {"bytes_per_launch": …, "source": "rocprofv3 --pmc …"}
+                traffic = json.load(f)       # {"bytes_per_launch": …, "source": "rocprofv3 --pmc …", "lib_src_hash": …}
+            # the PMC passes are offline: the figure only describes THIS run if it was taken on the binary that is loaded now
+            if traffic.get("lib_src_hash") != lib_src_hash:
+                traffic_note = (f"{os.path.relpath(tfile, ROOT)} was recorded on library src:{traffic.get('lib_src_hash')} but the loaded "
+                                f"library is src:{lib_src_hash}: dropped (re-record with tools/r06_profile.sh)")
+                traffic = None
         n_sampled = len(range(0, K, sample_every))
         if "gemm_bt" in stats:
             g = stats["gemm_bt"]
@@ -487,6 +542,36 @@ def main():
             line["roofline"]["measured_mfma_only_ceiling"] = {"value": MFMA_MEASURED_CEILING_TFLOPS, "unit": "TFLOP/s",
                                                               "frac": round(tf / MFMA_MEASURED_CEILING_TFLOPS, 4),
                                                               "source": "profiles/r02_power_clock_mfma_only.txt (register-only MFMA loop, pseudo-random fp16 operands, 1.9 GHz at 1.3 kW)"}
+            if traffic_note:
+                line["roofline"]["traffic_note"] = traffic_note
+            # the launches of the dominant kernel once more per problem: the four GEMMs of an image-tower block by name, then the rest
+            # by total time.  frac = 2MNK / average launch duration / peak, from the same dispatch timestamps as `achieved`.
+            Ti = args.batch * (1 + n_vpt + arch.grid ** 2)
+            dvw = arch.vision_width
+            names = {(Ti, 3 * dvw, dvw): "image QKV", (Ti, dvw, dvw): "image out-projection", (Ti, 4 * dvw, dvw): "image MLP up + GELU",
+                     (Ti, dvw, 4 * dvw): "image MLP down"}
+            per_kernel = []
+            for k, v in stats.items():
+                m = _re.match(r"g(\d+)x(\d+)x(\d+) e(\d+) s(\d+) f(\d+)$", k)
+                if not m:
+                    continue
+                Mq, Nq, Kq, eq, sq, fq = (int(x) for x in m.groups())
+                avg_us = 1e3 * v["ms"] / v["launches"]
+                per_kernel.append({"name": names.get((Mq, Nq, Kq), "other") + (" (dX)" if eq in (3, 6) else ""), "M": Mq, "N": Nq, "K": Kq, "epilogue": eq,
+                                   "operands": {0: "single", 1: "16-bit pair", 2: "mixed pair"}[sq], "ln_fold_consumer": bool(fq),
+                                   "launches_per_step": round(v["launches"] / n_sampled, 2), "avg_us": round(avg_us, 1),
+                                   "tflops": round(2.0 * Mq * Nq * Kq / avg_us / 1e6, 1),
+                                   "frac": round(2.0 * Mq * Nq * Kq / (avg_us * 1e-6) / (MFMA_PEAK_TFLOPS * 1e12), 4)})
+            per_kernel.sort(key=lambda r: -r["avg_us"] * r["launches_per_step"])
+            line["roofline"]["per_kernel"] = per_kernel[:12]
+            if "attention_fwd_image" in stats:
+                a = stats["attention_fwd_image"]
+                au = 1e3 * a["ms"] / a["launches"]
+                line["roofline"]["image_attention_fwd"] = {"launches_per_step": round(a["launches"] / n_sampled, 2), "avg_us": round(au, 1),
+                                                           "algorithmic_bytes": int(a["bytes"] / a["launches"]),
+                                                           "gb_per_s": round(a["bytes"] / a["launches"] / au / 1e3, 1),
+                                                           "frac_of_hbm_8tbs": round(a["bytes"] / a["launches"] / (au * 1e-6) / 8e12, 4),
+                                                           "mfma_frac": round(a["flops"] / a["launches"] / (au * 1e-6) / (MFMA_PEAK_TFLOPS * 1e12), 4)}
             if clock:
                 line["roofline"]["peak_at_measured_clock"] = round(sustained, 1)
                 line["roofline"]["frac_at_measured_clock"] = round(tf / sustained, 4)

@@ -72,10 +72,12 @@ int mvlpt_set_ln_fold(void* handle, int mode, int min_rows);
 int mvlpt_set_resid_packed(void* handle, int on);
 /* `vpt_dropout` of the reference (trainers/mvlpt.py:165, 424 and :77): the visual prompt rows are expanded over the batch and THEN
  * dropped out, so every image has its own mask.  masks = fp32 [n_layers, B, n_vpt, width] on the device, 0 or 1 / (1 - p): layer 0
- * belongs to the shallow prompts, layer l >= 1 to the deep prompts spliced in front of block l.  The NEXT mvlpt_image_fwd multiplies
- * the prompt rows it writes with them and mvlpt_image_bwd the gradients it sums over the batch; the caller keeps the buffer alive
- * until that backward and clears the setting with masks = NULL (evaluation, TRAINER.MVLPT.VPT.DROPOUT = 0). */
-int mvlpt_set_vpt_dropout(void* handle, const float* masks, int n_layers);
+ * belongs to the shallow prompts, layer l >= 1 to the deep prompts spliced in front of block l.  ONE-SHOT: the NEXT mvlpt_image_fwd
+ * checks the extents against its own (n_layers >= 1 + n_deep, batch, n_vpt; a mismatch is MVLPT_ERR_ARG), multiplies the prompt rows
+ * it writes with the masks, hands the pointer to ITS mvlpt_image_bwd (which multiplies the gradients it sums over the batch) and
+ * clears the setting — a later forward without a new call runs without dropout.  The caller keeps the buffer alive until that
+ * backward.  masks = NULL clears a pending setting. */
+int mvlpt_set_vpt_dropout(void* handle, const float* masks, int n_layers, int batch, int n_vpt, int width);
 /* Workspaces only grow, and a block that was outgrown is retired (not freed) so that no step ever meets a device-wide sync.
  * mvlpt_trim synchronises the device and releases the retired blocks: call it at an epoch boundary (e.g. after a one-off large
  * evaluation batch or class list). */
@@ -263,7 +265,9 @@ typedef struct MvlptKernelStat {
 int mvlpt_profile_begin(void* handle, int all_kernels);
 /* paused != 0: launches are not timed until resumed (bench.py samples every 4th step to keep the overhead ~1 %) */
 int mvlpt_profile_pause(void* handle, int paused);
-/* synchronises the recorded events, fills up to `max_stats` entries, returns the number written (or <0) */
+/* synchronises the recorded events, fills up to `max_stats` entries, returns the number written (or <0): first one entry per kernel
+ * class (busy_ms = union of the launch intervals), then the GEMM launches once more per problem, longest total time first, named
+ * "g<M>x<N>x<K> e<epilogue> s<operand format> f<folded consumer>" (busy_ms = ms = sum of the launch durations) */
 int mvlpt_profile_end(void* handle, MvlptKernelStat* stats, int max_stats);
 
 #ifdef __cplusplus

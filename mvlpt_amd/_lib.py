@@ -49,7 +49,7 @@ SIGNATURES = {
     "mvlpt_trim": (_i, [_vp]),
     "mvlpt_set_ln_fold": (_i, [_vp, _i, _i]),
     "mvlpt_set_resid_packed": (_i, [_vp, _i]),
-    "mvlpt_set_vpt_dropout": (_i, [_vp, _vp, _i]),
+    "mvlpt_set_vpt_dropout": (_i, [_vp, _vp, _i, _i, _i, _i]),
     "mvlpt_last_error": (C.c_char_p, [_vp]),
     "mvlpt_version": (C.c_char_p, []),
     "mvlpt_stream_create_cus": (_i, [_i, _i, C.POINTER(_vp)]),

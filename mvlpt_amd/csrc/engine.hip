@@ -17,6 +17,8 @@
 #include <cmath>
 #include <cstdio>
 #include <algorithm>
+#include <array>
+#include <map>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -141,7 +143,7 @@ constexpr int FOLD_NTP = 8;              // slots per row the buffers are sized 
 enum ProfClass { PC_GEMM = 0, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD, PC_GLUE, PC_HEAD, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm_bt", "attention_fwd", "attention_bwd", "layernorm_fwd", "layernorm_bwd",
                                            "glue", "head_logits_ce"};
-struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes, flops_exec; };
+struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes, flops_exec; int M = 0, N = 0, K = 0, epi = -1, split = 0, fold = 0; };
 
 struct Engine {
   MvlptArch arch{};
@@ -153,8 +155,12 @@ struct Engine {
   // packed residual stream: the fp16 image tower without prompts and without a backward carries x as hi (fp16, at the
   // same time the A operand behind every LayerNorm) + one byte instead of fp32 + a 16-bit copy.  MVLPT_RESID_PACKED / mvlpt_set_resid_packed
   int resid_packed = 0;      // off by default: one image in ~3 000 towers comes out 1e-3 off while the text tower runs on another stream (NOTES round 5)
-  const float* vpt_mask = nullptr;   // mvlpt_set_vpt_dropout: [layers, B, n_vpt, d] masks of the visual prompt rows, or null
-  int vpt_mask_layers = 0;
+  // mvlpt_set_vpt_dropout: [layers, B, n_vpt, d] masks of the visual prompt rows for the NEXT image_fwd (one-shot: the forward
+  // validates the geometry, takes the setting over as v_mask — what ITS backward uses — and clears it, so a stale pointer never
+  // reaches another forward or another user of the engine)
+  const float* vpt_mask = nullptr;
+  int vpt_mask_layers = 0, vpt_mask_B = 0, vpt_mask_n = 0, vpt_mask_d = 0;
+  const float* v_mask = nullptr;     // the masks of the forward whose activations are saved (null: none)
   bool lo8 = true;      // split towers of MVLPT_PREC_SPLIT_GRAD use the mixed pair (hi + e5m2 residual byte; MVLPT_SPLIT_LO8=0: 16-bit pairs)
   std::string err;
   TowerW vis, txt;
@@ -242,7 +248,7 @@ hipError_t gemm(Engine* E, int epi, const void* A, WRef Bt, int M, int N, int K,
       const double xa = a_split == 2 ? 1.5 : (a_split ? 2.0 : 1.0);
       E->prof.push_back(ProfRec{PC_GEMM, ea, eb, 2.0 * M * N * K,
                                 2.0 * ((double)M * K * xa + (double)N * K * (a_split == 2 ? 1.5 : 1.0)) + ob * M * N + (out2 ? 2.0 * M * N : 0),
-                                2.0 * M * N * K * xa});
+                                2.0 * M * N * K * xa, M, N, K, epi, a_split, (f && f->fold_part) ? 1 : 0});
     }
   }
   return launch_gemm(dt, epi, g, s, ea, eb);
@@ -572,6 +578,9 @@ const char* first_missing(Engine* E) {
 // when all frozen tensors are there (the first tower forward)
 int prepare_fold(Engine* E, hipStream_t s) {
   if (E->fold_ready) return 0;
+  // A REBUILD (frozen tensors reloaded, packed stream toggled) rewrites vectors the other tower — on another stream — may still be
+  // reading: drain the device first.  Rare and outside any step; the first build has no readers.
+  if (!E->vis.blocks.empty() && E->vis.blocks[0].qkv.fold_s) HIPCHK(E, hipDeviceSynchronize());
   for (TowerW* W : {&E->vis, &E->txt}) {
     const int d = W->width;
     for (Block& B : W->blocks) {
@@ -609,7 +618,14 @@ int prepare_fold(Engine* E, hipStream_t s) {
 // ================================================================================================ C ABI
 extern "C" {
 
-const char* mvlpt_version(void) { return "mvlpt_hip 0.1 (gfx950)"; }
+#ifndef MVLPT_SRC_HASH
+#define MVLPT_SRC_HASH "unknown"
+#endif
+#ifndef MVLPT_GIT_HASH
+#define MVLPT_GIT_HASH "nogit"
+#endif
+// "mvlpt_hip 0.1 (gfx950) src:<sha256 of csrc/*.hip csrc/*.h include/mvlpt_hip.h, 12 hex> git:<commit the tree was built in>"
+const char* mvlpt_version(void) { return "mvlpt_hip 0.1 (gfx950) src:" MVLPT_SRC_HASH " git:" MVLPT_GIT_HASH; }
 
 const char* mvlpt_last_error(void* h) { return h ? ((Engine*)h)->err.c_str() : g_create_err.c_str(); }
 
@@ -699,11 +715,14 @@ int mvlpt_set_ln_fold(void* h, int mode, int min_rows) {
   return 0;
 }
 
-int mvlpt_set_vpt_dropout(void* h, const float* masks, int n_layers) {
+int mvlpt_set_vpt_dropout(void* h, const float* masks, int n_layers, int batch, int n_vpt, int width) {
   Engine* E = (Engine*)h;
-  if (!E || (masks && n_layers <= 0)) return fail(E, MVLPT_ERR_ARG, "set_vpt_dropout: invalid argument");
+  if (!E) return MVLPT_ERR_ARG;
+  if (masks && (n_layers <= 0 || batch <= 0 || n_vpt <= 0 || width != E->arch.vision_width))
+    return fail(E, MVLPT_ERR_ARG, "set_vpt_dropout: masks are [n_layers, batch, n_vpt, vision_width], every extent positive");
   E->vpt_mask = masks;
   E->vpt_mask_layers = masks ? n_layers : 0;
+  E->vpt_mask_B = masks ? batch : 0; E->vpt_mask_n = masks ? n_vpt : 0; E->vpt_mask_d = masks ? width : 0;
   return 0;
 }
 
@@ -845,8 +864,14 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   if (st.fold) if (int rc = prepare_fold(E, s)) return rc;
 
   // vpt_dropout masks of layer l's prompt rows (mvlpt_set_vpt_dropout), or null
-  if (E->vpt_mask && (n_vpt <= 0 || E->vpt_mask_layers < 1 + n_deep)) return fail(E, MVLPT_ERR_ARG, "image_fwd: the prompt dropout masks do not cover every prompted layer");
-  auto vmask = [&](int l) -> const float* { return E->vpt_mask ? E->vpt_mask + (size_t)l * B * n_vpt * dv : nullptr; };
+  // the setting belongs to THIS forward (and its backward) only
+  const float* const masks = E->vpt_mask;
+  const int mask_layers = E->vpt_mask_layers, mask_B = E->vpt_mask_B, mask_n = E->vpt_mask_n;
+  E->vpt_mask = nullptr; E->vpt_mask_layers = 0; E->v_mask = nullptr;
+  if (masks && (n_vpt <= 0 || mask_layers < 1 + n_deep || mask_B != B || mask_n != n_vpt))
+    return fail(E, MVLPT_ERR_ARG, "image_fwd: the prompt dropout masks do not match this forward (layers >= 1 + n_deep, batch, n_vpt)");
+  E->v_mask = masks;
+  auto vmask = [&](int l) -> const float* { return masks ? masks + (size_t)l * B * n_vpt * dv : nullptr; };
   { ProfScope ps(E, s, PC_GLUE, 0, (double)npatch * E->Kp * 6.0);
     HIPCHK(E, launch_patchify(E->dt, image, image_dtype, patches, B, A.image_resolution, A.patch_size, E->Kp, s)); }
   HIPCHK(E, gemm(E, EPI_STORE32, patches, WRef{E->conv_w, 0, 0}, (int)npatch, dv, E->Kp, nullptr, nullptr, nullptr, pe, nullptr, s));
@@ -985,7 +1010,7 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
     if (l > 0 && E->v_ndeep > 0 && l <= E->v_ndeep) {
       ProfScope ps(E, s, PC_GLUE, 0, (double)B * n * dv * 10.0);
       HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt_deep + (size_t)(l - 1) * n * dv,
-                                          st.scale_dev, 1, s, xs, E->vpt_mask ? E->vpt_mask + (size_t)l * B * n * dv : nullptr));
+                                          st.scale_dev, 1, s, xs, E->v_mask ? E->v_mask + (size_t)l * B * n * dv : nullptr));
     }
     l_top = l - 1;
   } else {
@@ -1000,12 +1025,12 @@ int mvlpt_image_bwd(void* h, const float* dfeat, float* dvpt, float* dvpt_deep, 
     if (l > 0 && E->v_ndeep > 0 && l <= E->v_ndeep) {
       ProfScope ps(E, s, PC_GLUE, 0, (double)B * n * dv * 10.0);
       HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt_deep + (size_t)(l - 1) * n * dv,
-                                          st.scale_dev, 1, s, xs, E->vpt_mask ? E->vpt_mask + (size_t)l * B * n * dv : nullptr));
+                                          st.scale_dev, 1, s, xs, E->v_mask ? E->v_mask + (size_t)l * B * n * dv : nullptr));
     }
   }
   if (n > 0) {
     ProfScope ps(E, s, PC_GLUE, 0, (double)B * n * dv * 4.0);
-    HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt, st.scale_dev, 0, s, 0, E->vpt_mask));
+    HIPCHK(E, launch_reduce_prompt_rows(E->dt, st.dx32, st.dx16, B, Lv, dv, 1, n, dvpt, st.scale_dev, 0, s, 0, E->v_mask));
   }
   return 0;
 }
@@ -1477,6 +1502,8 @@ int mvlpt_profile_end(void* h, MvlptKernelStat* stats, int max_stats) {
   E->prof_on = false;
   MvlptKernelStat acc[PC_COUNT];
   for (int i = 0; i < PC_COUNT; ++i) { memset(&acc[i], 0, sizeof(acc[i])); snprintf(acc[i].name, sizeof(acc[i].name), "%s", kProfNames[i]); }
+  // ... and the GEMM launches once more per problem (M, N, K, epilogue, operand format, folded consumer): name "g<M>x<N>x<K> e<epi> s<split> f<fold>"
+  std::map<std::array<int, 6>, MvlptKernelStat> shapes;
   std::vector<std::pair<float, float>> iv[PC_COUNT];     // [start, end] in ms relative to the first recorded event
   hipEvent_t ref = E->prof.empty() ? nullptr : E->prof.front().a;
   for (const ProfRec& r : E->prof) {
@@ -1485,6 +1512,11 @@ int mvlpt_profile_end(void* h, MvlptKernelStat* stats, int max_stats) {
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
     acc[r.cls].launches += 1; acc[r.cls].ms += ms; acc[r.cls].flops += r.flops; acc[r.cls].bytes += r.bytes;
     acc[r.cls].flops_executed += r.flops_exec;
+    if (r.cls == PC_GEMM && r.M > 0) {
+      MvlptKernelStat& q = shapes[{r.M, r.N, r.K, r.epi, r.split, r.fold}];
+      if (!q.launches) { memset(&q, 0, sizeof(q)); snprintf(q.name, sizeof(q.name), "g%dx%dx%d e%d s%d f%d", r.M, r.N, r.K, r.epi, r.split, r.fold); }
+      q.launches += 1; q.ms += ms; q.busy_ms += ms; q.flops += r.flops; q.bytes += r.bytes; q.flops_executed += r.flops_exec;
+    }
     if (r.a == ref || hipEventElapsedTime(&t0, ref, r.a) == hipSuccess) iv[r.cls].push_back({t0, t0 + ms});
   }
   for (int c = 0; c < PC_COUNT; ++c) {                    // union of the intervals per class
@@ -1500,6 +1532,10 @@ int mvlpt_profile_end(void* h, MvlptKernelStat* stats, int max_stats) {
   }
   int n = 0;
   for (int i = 0; i < PC_COUNT && n < max_stats; ++i) if (acc[i].launches) stats[n++] = acc[i];
+  std::vector<MvlptKernelStat> by_time;
+  for (auto& kv : shapes) by_time.push_back(kv.second);
+  std::sort(by_time.begin(), by_time.end(), [](const MvlptKernelStat& x, const MvlptKernelStat& y) { return x.ms > y.ms; });
+  for (size_t i = 0; i < by_time.size() && n < max_stats; ++i) stats[n++] = by_time[i];
   E->prof.clear(); E->ev_used = 0;
   return n;
 }

@@ -64,6 +64,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   constexpr bool CAN_FOLD = epi_folds(EPI);
   [[maybe_unused]] char* const xlds = smem + NS * STAGE;        // LayerNorm folding: XLDS_BYTES(_WIDE) behind the ring (when launched with them)
   [[maybe_unused]] char* const xtab = xlds + xlds_tab(g.fold_ntp);
+  // Debug builds of the stress tools (tools/fold_consumer_repro.py): every register / every LDS byte of the workgroup holds a
+  // signalling pattern before the kernel's first instruction of its own — a read of anything the kernel did not write shows up
+  // as a NaN at a position that names it, with or without a partner on the other stream.
+#ifdef MVLPT_DBG_POISON_VGPR
+  if constexpr (BM_ == 128 && NW == 4 && NS == 2) {      // (v1..v199: the geometry with 256 registers per wave to spare)
+#include MVLPT_DBG_POISON_VGPR
+  }
+#endif
+#ifdef MVLPT_DBG_POISON_LDS
+  {
+    const int bytes = NS * STAGE + (CAN_FOLD ? xlds_bytes(g.fold_ntp) : (epi_ln_producer(EPI) ? XLDS_BYTES : 0));
+    for (int i = threadIdx.x; i < bytes / 4; i += NW * 64) ((unsigned*)smem)[i] = 0x7fc0beefu;
+    __syncthreads();
+  }
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

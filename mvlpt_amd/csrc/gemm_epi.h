@@ -82,6 +82,19 @@ __device__ __forceinline__ void fold_build_coef(const GemmArgs& g, char* xl, cha
 // (tools/fold_consumer_repro.py; the same code on scalar fmas: 0 of 360 launches; NOTES round 5).  v_pk_fma_f32 is not faster than
 // two v_fma_f32 on gfx950, so nothing is lost.  (Bit-identical results: both forms are fused.)
 __device__ __forceinline__ f32x4 fold_apply(float fa, float fcc, const f32x4& acc, const f32x4& colsum, const f32x4& bias2) {
+#ifdef MVLPT_FOLD_PK      // the round-5 form that failed (debug builds of the reproducer only): 1 as it was; 2 every input complete and
+  {                       // 16 wait states old before the arithmetic; 3 the results 8 wait states old before their first use
+    f32x4 a = acc;
+#if MVLPT_FOLD_PK == 2
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" : "+v"(a), "+v"(fa), "+v"(fcc));
+#endif
+    f32x4 r = fa * a + (fcc * colsum + bias2);
+#if MVLPT_FOLD_PK == 3
+    asm volatile("s_nop 7" : "+v"(r));
+#endif
+    return r;
+  }
+#endif
   f32x4 r;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {

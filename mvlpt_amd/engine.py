@@ -113,13 +113,15 @@ class Engine:
 
     def set_vpt_dropout(self, masks: Optional[torch.Tensor]) -> None:
         """Per-image dropout masks of the visual prompt rows for the next image_fwd / image_bwd pair (include/mvlpt_hip.h:
-        mvlpt_set_vpt_dropout): fp32 [n_layers, B, n_vpt, width], or None to clear.  The engine keeps the tensor alive."""
+        mvlpt_set_vpt_dropout): fp32 [n_layers, B, n_vpt, width], or None to clear.  One-shot: the next image_fwd consumes the setting
+        (and keeps the tensor alive for its backward); a forward without a new call runs without dropout."""
         if masks is not None:
             masks = _req(masks, torch.float32, "vpt dropout masks")
             if masks.dim() != 4 or masks.shape[-1] != self.arch.vision_width:
                 raise ValueError("vpt dropout masks must be [n_layers, B, n_vpt, vision_width]")
         self._vpt_masks = masks
-        _lib.check(lib.mvlpt_set_vpt_dropout(self.h, _ptr(masks), 0 if masks is None else int(masks.shape[0])), self.h, "set_vpt_dropout")
+        sh = (0, 0, 0, 0) if masks is None else tuple(int(v) for v in masks.shape)
+        _lib.check(lib.mvlpt_set_vpt_dropout(self.h, _ptr(masks), *sh), self.h, "set_vpt_dropout")
 
     def set_ln_fold(self, mode: int, min_rows: int = 4096) -> None:
         """LayerNorm folding (include/mvlpt_hip.h: mvlpt_set_ln_fold): 0 off, 1 image tower, 2 both towers."""
@@ -180,6 +182,8 @@ class Engine:
         _lib.check(lib.mvlpt_image_fwd(self.h, _ptr(image), _TORCH2DT[image.dtype], _ptr(vpt), _ptr(vpt_deep), n_vpt, n_deep, B,
                                        _ptr(feat), int(save_for_bwd), _stream()), self.h, "image_fwd")
         self._img_state = (n_vpt, n_deep, B) if save_for_bwd else None
+        # the setting was one-shot: this forward consumed it; its backward reads the buffer, so the tensor stays alive until then
+        self._vpt_masks_saved, self._vpt_masks = (m if save_for_bwd else None), None
         return feat
 
     @_on_device
@@ -300,8 +304,8 @@ class Engine:
 
     @_on_device
     def profile_end(self) -> Dict[str, dict]:
-        arr = (_lib.MvlptKernelStat * 16)()
-        n = lib.mvlpt_profile_end(self.h, arr, 16)
+        arr = (_lib.MvlptKernelStat * 64)()
+        n = lib.mvlpt_profile_end(self.h, arr, 64)
         if n < 0:
             raise RuntimeError("profile_end failed")
         return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes,

@@ -5,6 +5,7 @@ Run in the build container only (needs /root/reference; see oracle/ref_shim.py):
     python oracle/make_golden.py            # all fixtures
     python oracle/make_golden.py tiny       # only the tiny-arch ones
     python oracle/make_golden.py vptopt     # VPT.PROJECT / VPT.DROPOUT cases (tiny arch)
+    python oracle/make_golden.py ctxinit    # COOP.CTX_INIT (context initialised from words) cases (tiny arch)
 
 The reference's `trainers.mvlpt.CustomCLIP` (trainers/mvlpt.py:517-583) is instantiated on a
 `clip.model.CLIP` (clip/model.py:239-322) whose weights come from OUR deterministic generator
@@ -159,6 +160,9 @@ def run_case(mv, clip_model, *, name, image_size, classnames, B, case_seed, soft
         d["meta_vpt_dropout"] = np.float64(cfgkw["vpt_dropout"])
     if int(cfgkw.get("vpt_project", -1)) > -1:
         d["meta_vpt_project"] = np.int64(cfgkw["vpt_project"])
+    if cfgkw.get("coop_ctx_init"):
+        d["meta_coop_ctx_init"] = np.array(cfgkw["coop_ctx_init"])
+        d["meta_coop_n_ctx_cfg"] = np.int64(cfgkw["coop_n_ctx"])      # what the config asked for (the words decide: trainers/mvlpt.py:207)
     if task is not None:
         d["task"] = task.numpy().astype(np.int64)
         d["task_start"] = cc.class_index_pertask_start.numpy().astype(np.int64)
@@ -217,6 +221,23 @@ def make_vpt_options(mv, cm):
     run_case(mv, clip_model, name="tiny_vpt_project_dropout", case_seed=42, vpt_n_ctx=3, vpt_deep=True, vpt_project=24,
              vpt_dropout=0.25, **common)
     run_case(mv, clip_model, name="tiny_vpt_shallow_dropout", case_seed=43, vpt_n_ctx=2, vpt_deep=False, vpt_dropout=0.5, **common)
+
+
+def make_ctx_init(mv, cm):
+    """`ctxinit`: TRAINER.MVLPT.COOP.CTX_INIT (trainers/mvlpt.py:203-212; the reference's *_ctxv1.yaml configs): the context vectors
+    start as the token embeddings of the given words and their count overrides COOP.N_CTX.  The fixture stores the initial `ctx`
+    (param_ctx: nothing touches it before the forward) next to the usual outputs.  VPT.CTX_INIT raises in the reference (:180-182)."""
+    arch = ARCHS["tiny"]
+    clip_model, _ = build_ref_clip(cm, arch, TINY_SEED)
+    common = dict(image_size=arch.image_resolution, classnames=CLASSNAMES[:5], B=4)
+    run_case(mv, clip_model, name="tiny_coop_ctxinit", case_seed=44, coop_n_ctx=16, coop_ctx_init="a_photo_of_a", class_token_position="end", **common)
+    run_case(mv, clip_model, name="tiny_upt_ctxinit", case_seed=45, coop_n_ctx=2, coop_ctx_init="a photo of", vpt_n_ctx=2, vpt_deep=True,
+             project_dim=64, **common)
+    try:
+        mv.CustomCLIP(ref_shim.make_cfg(input_size=arch.image_resolution, vpt_n_ctx=2, vpt_ctx_init="a photo"), CLASSNAMES[:5], clip_model, dm=None)
+        raise AssertionError("the reference accepted VPT.CTX_INIT")
+    except ValueError as e:
+        print(f"[golden] VPT.CTX_INIT -> ValueError({e})")
 
 
 def make_train_steps(mv, clip_model, arch):
@@ -452,6 +473,8 @@ def main():
         make_coop_trainer(cm)
     if "vptopt" in which:
         make_vpt_options(mv, cm)
+    if "ctxinit" in which:
+        make_ctx_init(mv, cm)
 
 
 if __name__ == "__main__":

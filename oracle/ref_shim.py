@@ -92,7 +92,7 @@ def load_reference():
 
 def make_cfg(*, coop_n_ctx=0, vpt_n_ctx=0, vpt_deep=True, csc=False, class_token_position="middle",
              cut_contextlen=False, input_size=224, project_method="transformer", project_dim=128,
-             label_pertask=False, prec="fp32", vpt_project=-1, vpt_dropout=0.0):
+             label_pertask=False, prec="fp32", vpt_project=-1, vpt_dropout=0.0, coop_ctx_init="", vpt_ctx_init=""):
     """SimpleNamespace tree with exactly the keys the hot path reads
     (train.py:105-169, trainers/mvlpt.py:139-325,517-538)."""
     ns = SimpleNamespace
@@ -100,8 +100,8 @@ def make_cfg(*, coop_n_ctx=0, vpt_n_ctx=0, vpt_deep=True, csc=False, class_token
         TRAINER=ns(
             MVLPT=ns(
                 PREC=prec, PROJECT_METHOD=project_method, PROJECT_DIM=project_dim,
-                VPT=ns(N_CTX=vpt_n_ctx, CSC=False, CTX_INIT="", DROPOUT=vpt_dropout, PROJECT=vpt_project, DEEP=vpt_deep),
-                COOP=ns(N_CTX=coop_n_ctx, CSC=csc, CTX_INIT="", CLASS_TOKEN_POSITION=class_token_position),
+                VPT=ns(N_CTX=vpt_n_ctx, CSC=False, CTX_INIT=vpt_ctx_init, DROPOUT=vpt_dropout, PROJECT=vpt_project, DEEP=vpt_deep),
+                COOP=ns(N_CTX=coop_n_ctx, CSC=csc, CTX_INIT=coop_ctx_init, CLASS_TOKEN_POSITION=class_token_position),
                 COCOOP=ns(N_CTX=0, CTX_INIT="", PREC="fp16"),
             ),
             CUT_CONTEXTLEN=cut_contextlen, ACT_CKPT=1,

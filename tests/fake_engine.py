@@ -19,11 +19,12 @@ class OracleEngine:
         self._vpt_masks = masks
 
     def image_fwd(self, image, vpt=None, vpt_deep=None, save_for_bwd=False):
+        masks, self._vpt_masks = getattr(self, "_vpt_masks", None), None      # one-shot, as in the HIP engine
         with torch.no_grad():
             feat, self._ictx = O.image_encoder_fwd(self.sd, image, None if vpt is None else vpt.detach().reshape(1, -1, vpt.shape[-1]),
                                                    None if vpt_deep is None else vpt_deep.detach(),
                                                    heads=self.arch.vision_heads, need_bwd=save_for_bwd,
-                                                   vpt_masks=getattr(self, "_vpt_masks", None))
+                                                   vpt_masks=masks)
         return feat
 
     def image_bwd(self, dfeat):

@@ -358,5 +358,13 @@ def test_gemm_ragged_last_round_full_size(M, N, K, epi):
     assert relerr(out0, want) < tol
     # the LAST rows are the ones the split round produces: check them on their own as well
     assert relerr(out0[-2048:], want[-2048:]) < tol
+    # ... and against the ORACLE, not only the library matmul: the last 4096 rows (the ragged round) in fp64 on the host
+    sl = slice(M - 4096, M)
+    o64 = A[sl].double().cpu() @ Bt.double().cpu().t() + bias.double().cpu()
+    if epi == "resid":
+        o64 = o64 + resid[sl].double().cpu()
+    elif epi == "gelu":
+        o64 = O.quick_gelu(o64)
+    assert relerr(out0[sl].cpu().double(), o64) < tol
     for _ in range(5):
         assert torch.equal(run(), out0)

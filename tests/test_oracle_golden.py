@@ -46,7 +46,7 @@ def test_tiny_case_matches_reference(name):
     for k, g in G.items():
         scale = float(g.abs().max()) + 1e-12
         err = float((res.grads[k] - g).abs().max()) / scale
-        assert err < 5e-4, f"{name}: grad {k} rel-to-max err {err:.3e}"
+        assert err < 5e-5, f"{name}: grad {k} rel-to-max err {err:.3e}"      # measured <= 4.8e-6 (fp32 on both sides)
 
 
 def test_eot_is_argmax_of_token_ids():

@@ -1,10 +1,16 @@
 #!/bin/bash
 # A second copy of the library with extra compiler flags (debug / ablation builds), same ABI: tools/build_variant.sh <name> <flags...>
 # -> mvlpt_amd/libvar_<name>.so (git-ignored, travels with gpurun); load it with MVLPT_HIP_LIB=$PWD/mvlpt_amd/libvar_<name>.so
+# ONLY_GEMM=1: recompile gemm.hip / gemm_duo.hip only and link the other objects of the product build (build/obj)
 set -e
 name=$1; shift
 O=build/var_$name; mkdir -p $O
-for f in gemm gemm_duo norm attention attention_stream attention32 glue preprocess engine; do
+files="gemm gemm_duo norm attention attention_stream attention32 glue preprocess engine"
+if [ -n "$ONLY_GEMM" ]; then
+  files="gemm"
+  for f in gemm_duo norm attention attention_stream attention32 glue preprocess engine; do cp build/obj/$f.o $O/$f.o; done
+fi
+for f in $files; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result -Wno-inline-asm "$@" -c mvlpt_amd/csrc/$f.hip -o $O/$f.o &
 done
 wait

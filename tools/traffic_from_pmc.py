@@ -17,7 +17,17 @@ g = [k for k in rd if ("gemm_bt_kernel" in k or "gemm_bt_phased_kernel" in k or 
 n = sum(rd[k][0] for k in g); fr = sum(rd[k][1] for k in g)
 nw = sum(wr[k][0] for k in g if k in wr); fw = sum(wr[k][1] for k in g if k in wr)
 what = sys.argv[3] if len(sys.argv) > 3 else "headline bench step"
-out = {"kernel": f"gemm_bt_kernel + gemm_bt_phased_kernel + gemm_pc_kernel + gemm_pcp_kernel (all epilogues/geometries, {what})", "launches_sampled": n,
+# identity of the binary the counters were taken on (mvlpt_version(): "... src:<hash> git:<commit>"); bench.py drops the figure when
+# the library it loads is another one
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from mvlpt_amd import _lib
+    version = _lib.lib.mvlpt_version().decode()
+except Exception as e:      # noqa: BLE001
+    version = f"unknown ({e})"
+out = {"lib_version": version, "lib_src_hash": (re.search(r"src:(\w+)", version) or [None, None])[1],
+       "kernel": f"gemm_bt_kernel + gemm_bt_phased_kernel + gemm_pc_kernel + gemm_pcp_kernel (all epilogues/geometries, {what})", "launches_sampled": n,
        "FETCH_SIZE_kb_avg_raw": round(fr / n, 1), "WRITE_SIZE_kb_avg_raw": round(fw / nw, 1),
        "bytes_per_launch": int((2.0 * fr / n + fw / nw) * 1024),
        "correction": "2 x FETCH_SIZE (gfx950 half-count of 16 B/lane reads) + WRITE_SIZE; counters in KB; includes Infinity-Cache hits",
