@@ -82,6 +82,13 @@ int mvlpt_set_vpt_dropout(void* handle, const float* masks, int n_layers, int ba
  * mvlpt_trim synchronises the device and releases the retired blocks: call it at an epoch boundary (e.g. after a one-off large
  * evaluation batch or class list). */
 int mvlpt_trim(void* handle);
+/* DEBUG (tools/tower_stage_probe.py; off by default, no cost when off): while enabled, mvlpt_image_fwd adds one 64-bit fingerprint
+ * (position-weighted sum of the 32-bit words) per intermediate — patches, patch embedding, token assembly, and per packed block qkv,
+ * attention output, the stream + row statistics behind each of the two updates, the MLP activations — to a device array it clears at
+ * its start.  The call synchronises the device, copies up to max_out fingerprints of the LAST forward to host_out (may be NULL),
+ * switches the recording on / off and returns the number copied.  Two runs on the same input agree entry by entry; the first entry
+ * that differs names the kernel. */
+int mvlpt_debug_checksums(void* handle, int enable, unsigned long long* host_out, int max_out);
 int mvlpt_destroy(void* handle);
 const char* mvlpt_last_error(void* handle); /* handle may be NULL for create() failures */
 const char* mvlpt_version(void);
@@ -202,6 +209,11 @@ int mvlpt_op_gemm_folded(int dtype, int epi, const void* A16, int a_split, const
 int mvlpt_op_fold_weight(const void* W16, int ld, const float* gamma, void* Wg16, int ldg, float* colsum, int N, int K,
                          mvlpt_stream_t stream);
 int mvlpt_op_respk_pack(const float* x, void* hi, uint8_t* lo, float* part, int ntp, int rows, int d, mvlpt_stream_t stream);
+/* the tower entry of the packed stream (ImageEncoder.forward's class token + positional embedding + ln_pre, trainers/mvlpt.py:60-66,
+ * straight into the packed format): rows [batch, 1 + grid2, d] from patch_emb [batch * grid2, d], cls [d], pos [1 + grid2, d];
+ * part as in respk_pack (the statistics of block 0's ln_1) */
+int mvlpt_op_assemble_packed(const float* patch_emb, const float* cls, const float* pos, const float* ln_g, const float* ln_b, void* hi,
+                             uint8_t* lo, float* part, int ntp, int batch, int grid2, int d, mvlpt_stream_t stream);
 int mvlpt_op_respk_unpack(const void* hi, const uint8_t* lo, int row_mul, float* out, int rows, int d, mvlpt_stream_t stream);
 int mvlpt_op_gemm_residp(const void* A, const void* Bt, int ldb, int M, int N, int K, const float* bias, const void* hi_in,
                          const uint8_t* lo_in, void* hi_out, uint8_t* lo_out, float* part, int ntp, int* nt, mvlpt_stream_t stream);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mvlpt_destroy": (_i, [_vp]),
     "mvlpt_set_precision": (_i, [_vp, _i]),
     "mvlpt_trim": (_i, [_vp]),
+    "mvlpt_debug_checksums": (_i, [_vp, _i, C.POINTER(C.c_uint64), _i]),
     "mvlpt_set_ln_fold": (_i, [_vp, _i, _i]),
     "mvlpt_set_resid_packed": (_i, [_vp, _i]),
     "mvlpt_set_vpt_dropout": (_i, [_vp, _vp, _i, _i, _i, _i]),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "mvlpt_op_gemm_folded": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "mvlpt_op_fold_weight": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "mvlpt_op_respk_pack": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mvlpt_op_assemble_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mvlpt_op_respk_unpack": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),
     "mvlpt_op_gemm_residp": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_int), _vp]),
     "mvlpt_op_layernorm_fwd_mixed": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp]),

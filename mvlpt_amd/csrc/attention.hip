@@ -147,6 +147,175 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
+// ======================================================================================= forward, persistent over heads
+// The headline's shape (ViT-B/16: L = 197..208, 13 key tiles, not causal, full sequences, N * H >> CUs).  attn_fwd_kernel above runs
+// one 4-wave workgroup per (image, head): staging (52 KiB), arithmetic and stores of a head are serial inside the workgroup and only
+// overlap across the three workgroups of a CU, and 13 query tiles on 4 waves leave a quarter of three waves' time unused: 81.5 us for
+// 310 MB = 3.8 TB/s.  Here ONE workgroup per CU walks the (image, head) list — the scheme that bought +14 % for the pair kernel
+// (attention32.hip attn32p_fwd_kernel): seven waves with two query tiles each (14 slots for 13 tiles), three 26-KiB buffers in
+// rotation so that K of head i+1 lands during all of head i and V of head i+1 behind its S phase (the buffer K_i just left), Q of head
+// i+1 fetched into the registers Q_i leaves.  Both tiles of a wave share every K / V^T fragment (half the LDS reads per score).
+// Waits are counted by hand (LDS-DMA from inline asm: dma_raw): at the top of a head everything but the previous head's output stores.
+constexpr int PNT = 13, PNW = 7, PROWS = PNT * 16, PIMG = PROWS * 128, PLDS = 3 * PIMG;
+template <typename T>
+__device__ __forceinline__ void stage_p(char* buf, const T* src, size_t ld, int L, int wave, int lane) {
+  const int srow = lane >> 3, chunk = (lane & 7) ^ srow;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {      // 26 slabs of 8 rows on 7 waves: four requests each (the last two waves repeat slab 25: same bytes)
+    int sl = wave + PNW * i;
+    sl = sl < PROWS / 8 ? sl : PROWS / 8 - 1;
+    int row = sl * 8 + srow;
+    row = row < L ? row : L - 1;
+    dma_raw<16>(src + (size_t)row * ld + chunk * 8, buf + sl * 1024);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(PNW * 64) void attn_fwdp_kernel(AttnArgs a, int total) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  using v8 = typename Vec<T>::v8;
+  using v4 = typename Vec<T>::v4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+  const int L = a.L, H = a.H, d = H * 64, G = gridDim.x;
+  const size_t ld = 3 * (size_t)d;
+  const bool two = wave + PNW < PNT;         // the wave's second tile exists (waves 0-5)
+  auto head_base = [&](int item) -> const T* {
+    const int n = item / H, h = item - n * H;
+    return (const T*)a.qkv + (size_t)n * L * ld + h * 64;
+  };
+  auto load_q = [&](const T* base, v8 (&Q)[2][2]) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int q = (wave + o * PNW) * 16 + fr;
+      const T* qp = base + (size_t)(q < L ? q : L - 1) * ld + fg * 8;
+      Q[o][0] = *(const v8*)qp;
+      Q[o][1] = *(const v8*)(qp + 32);
+    }
+  };
+  int item = blockIdx.x;
+  if (item >= total) return;
+  int kbuf = 0;
+  v8 Q[2][2];
+  {
+    const T* base = head_base(item);
+    stage_p<T>(sm, base + d, ld, L, wave, lane);               // K_0
+    stage_p<T>(sm + PIMG, base + 2 * d, ld, L, wave, lane);    // V_0
+    load_q(base, Q);
+  }
+  constexpr float SC2 = 0.125f * 1.4426950408889634f;           // 1/sqrt(64) * log2(e): softmax in base 2
+  const bool want_lse = a.lse != nullptr;
+  for (bool first = true; item < total; item += G, first = false) {
+    const int n = item / H, h = item - n * H;
+    char* const Kb = sm + kbuf * PIMG;
+    char* const Vb = sm + (kbuf + 1 >= 3 ? kbuf - 2 : kbuf + 1) * PIMG;
+    char* const Nb = sm + (kbuf + 2 >= 3 ? kbuf - 1 : kbuf + 2) * PIMG;
+    const int next = item + G;
+    // everything this wave requested has landed, except (vmcnt retires in order) its output stores of the previous head
+    if (first || want_lse) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // everybody's pieces of K_i, V_i are in; everybody is done with V_(i-1)
+    // (the compiler's own vmcnt waits for the Q fragments must sit HERE, in front of the DMA it does not see: attention32.hip)
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) asm volatile("" ::"v"(Q[o][ks]));
+    if (next < total) stage_p<T>(Nb, head_base(next) + d, ld, L, wave, lane);          // K_(i+1)
+    // ---- S^T = K Q^T of both own tiles against every key tile; the K fragments of tile kt + 1 travel under tile kt's MFMAs
+    f32x4 S[2][PNT];
+    v8 kf[2], kn[2];
+    auto load_k = [&](int kt, v8 (&f)[2]) { f[0] = frag_rows<T>(Kb, kt, 0, fr, fg); f[1] = frag_rows<T>(Kb, kt, 1, fr, fg); };
+    load_k(0, kf);
+#pragma unroll
+    for (int kt = 0; kt < PNT; ++kt) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < PNT) load_k(kt + 1, kn);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        S[o][kt] = mfma16<T>(kf[0], Q[o][0], f32x4{0.f, 0.f, 0.f, 0.f});
+        S[o][kt] = mfma16<T>(kf[1], Q[o][1], S[o][kt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      kf[0] = kn[0]; kf[1] = kn[1];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // K_i is dead
+    if (next < total) {
+      const T* nb = head_base(next);
+      stage_p<T>(Kb, nb + 2 * d, ld, L, wave, lane);                                    // V_(i+1)
+      load_q(nb, Q);                                                                    // Q_(i+1): Q_i is dead too
+    }
+    // ---- softmax of both tiles (only the last key tile can hold keys past the sequence)
+    float mx[2], sum[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[o][PNT - 1][r] = (PNT - 1) * 16 + 4 * fg + r < L ? S[o][PNT - 1][r] : -INFINITY;
+      mx[o] = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < PNT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx[o] = fmaxf(mx[o], S[o][kt][r]);
+      mx[o] = quad_max(mx[o]);
+      const float msc = mx[o] * SC2;
+      sum[o] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < PNT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { S[o][kt][r] = __builtin_amdgcn_exp2f(fmaf(S[o][kt][r], SC2, -msc)); sum[o] += S[o][kt][r]; }
+      sum[o] = quad_sum(sum[o]);
+    }
+    // ---- O^T = V^T P^T: every V^T fragment feeds both tiles; the fragment of the next (block, column tile) travels under the MFMAs
+    f32x4 O[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) O[o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NKB = (PNT + 1) / 2;
+    v8 vf, vn;
+    auto load_v = [&](int kb, int dt) -> v8 { return 2 * kb + 1 >= PNT ? frag_vt_half<T>(Vb, kb, dt, fr, fg) : frag_vt<T>(Vb, kb, dt, fr, fg); };
+    vf = load_v(0, 0);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      v8 pf[2];
+#pragma unroll
+      for (int o = 0; o < 2; ++o) pf[o] = 2 * kb + 1 < PNT ? pack8<T>(S[o][2 * kb], S[o][2 * kb + 1 < PNT ? 2 * kb + 1 : 0]) : pack8<T>(S[o][2 * kb], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (dt + 1 < 4) vn = load_v(kb, dt + 1);
+        else if (kb + 1 < NKB) vn = load_v(kb + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) O[o][dt] = mfma16<T>(vf, pf[o], O[o][dt]);
+        __builtin_amdgcn_sched_barrier(0);
+        vf = vn;
+      }
+    }
+    // ---- outputs: four 8-byte stores per existing tile (+ lse)
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      if (o == 1 && !two) continue;
+      const int q = (wave + o * PNW) * 16 + fr;
+      if (q < L) {
+        const float inv = 1.0f / sum[o];
+        T* op = (T*)a.out + ((size_t)n * L + q) * d + h * 64 + fg * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          v4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = from_f32<T>(O[o][dt][e] * inv);
+          if (a.flags & 2) __builtin_nontemporal_store(w, (v4*)(op + dt * 16));
+          else *(v4*)(op + dt * 16) = w;
+        }
+        if (want_lse && fg == 0) a.lse[((size_t)n * H + h) * L + q] = (mx[o] * SC2 + log2f(sum[o])) * 0.6931471805599453f;
+      }
+    }
+    kbuf = kbuf + 2 >= 3 ? kbuf - 1 : kbuf + 2;
+  }
+}
+
 // ======================================================================================= backward A: dQ (+ delta)
 // per query tile:  S^T, P^T = exp(S^T*scale - lse), dP^T = V dO^T, dS^T = P^T (dP^T - delta) * scale,
 //                  dQ^T = K^T dS^T.   LDS: K rows, V rows (DMA-staged); K^T fragments by transpose-read.
@@ -540,6 +709,22 @@ hipError_t launch_attn_fwd(int dtype, const AttnArgs& a_, hipStream_t s) {
   if (a.L <= 0 || a.L > attn_max_len() || a.N <= 0) return hipErrorInvalidValue;
   if (use_stream(a.L, false)) return launch_attn_fwd_stream(dtype, a, s);
   static const int odd_ok = [] { const char* e = getenv("MVLPT_ATTN_ODD"); return e ? atoi(e) : 1; }();
+  // persistent variant for the headline's shape: 13 key tiles, full sequences, at least two heads per compute unit of the stream
+  static const int persist = [] { const char* e = getenv("MVLPT_ATTN_PERSIST"); return e ? atoi(e) : 1; }();
+  if (persist && !a.causal && a.q_rows <= 0 && (a.L + 15) / 16 == PNT && (dtype == DT_F16 || dtype == DT_BF16)) {
+    const int total = a.N * a.H, cus = stream_cus(s);
+    if (total >= 2 * cus) {
+      static bool set = false;
+      if (!set) {
+        hipFuncSetAttribute((const void*)attn_fwdp_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+        hipFuncSetAttribute((const void*)attn_fwdp_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+        set = true;
+      }
+      if (dtype == DT_F16) hipLaunchKernelGGL((attn_fwdp_kernel<f16>), dim3(cus), dim3(PNW * 64), PLDS, s, a, total);
+      else hipLaunchKernelGGL((attn_fwdp_kernel<bf16>), dim3(cus), dim3(PNW * 64), PLDS, s, a, total);
+      return hipGetLastError();
+    }
+  }
   int nkt = nkt_for(a.L);
   if (odd_ok && !a.causal && (a.L + 15) / 16 == 13) nkt = 13;
   if (dtype == DT_F16) return a.causal ? fwd_n<f16, true>(nkt, a, s) : fwd_n<f16, false>(nkt, a, s);

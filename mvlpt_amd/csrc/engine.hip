@@ -188,6 +188,8 @@ struct Engine {
   int hB = 0, hC = 0; float h_scale = 0.f; const int32_t *h_lo = nullptr, *h_hi = nullptr;
   float *imn = nullptr, *txn = nullptr, *inorm = nullptr, *tnorm = nullptr;
   // profiling
+  // mvlpt_debug_checksums: one 64-bit fingerprint per intermediate of the image tower (debug; off by default)
+  unsigned long long* dbg_ck = nullptr; int dbg_ck_n = 0; bool dbg_ck_on = false;
   bool prof_on = false, prof_all = false; std::vector<ProfRec> prof; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
 };
 
@@ -214,6 +216,12 @@ struct ProfScope {
   }
   ~ProfScope() { if (on) (void)hipEventRecord(b, s); }
 };
+
+constexpr int DBG_CK_MAX = 256;
+static void dbg_ck(Engine* E, const void* p, size_t bytes, hipStream_t s) {
+  if (!E->dbg_ck_on || !E->dbg_ck || E->dbg_ck_n >= DBG_CK_MAX) return;
+  (void)launch_checksum(p, bytes, E->dbg_ck + E->dbg_ck_n++, s);
+}
 
 // ------------------------------------------------------------------------------------------------ kernel wrappers
 // LayerNorm folding of one GEMM call (GemmArgs::ln_* / fold_*)
@@ -447,21 +455,26 @@ int block_fwd_packed(Engine* E, const TowerW& W, TowerState& st, int l, hipStrea
   Fold fq = fold_consumer(st, 0, B.qkv), fo, ff, fp;
   fq.fold_colsum = B.qkv.fold_sg;
   HIPCHK(E, gemm(E, EPI_STORE16, hi, B.qkv.fwg(), T, 3 * d, d, B.qkv.fold_b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, 0, &fq));
+  dbg_ck(E, st.qkv[l], (size_t)T * 3 * d * 2, s);
   {
     AttnArgs a{st.qkv[l], st.attn[l], nullptr, st.N, st.L, st.H, st.causal ? 1 : 0};
     const double fl = 4.0 * st.L * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0);
     ProfScope ps(E, s, PC_ATTN_FWD, fl, (double)T * d * 2.0 * 4.0);
     HIPCHK(E, launch_attn_fwd(E->dt, a, s));
   }
+  dbg_ck(E, st.attn[l], (size_t)T * d * 2, s);
   if (!fold_producer(E, st, 1, T, d, d, B.ln2, s, &fo)) return fail(E, MVLPT_ERR_STATE, "packed residual stream: out-projection cannot produce the ln_2 statistics");
   fo.rp_hi_in = hi; fo.rp_lo_in = lo; fo.rp_lo_out = lo;
   HIPCHK(E, gemm(E, EPI_RESIDP_LN, st.attn[l], B.o.fw(), T, d, d, B.o.b, nullptr, nullptr, hi, nullptr, s, -1, 0, &fo));
+  dbg_ck(E, hi, (size_t)T * d * 3, s); dbg_ck(E, fo.ln_part, (size_t)T * fo.ln_ntp * 8, s);
   ff = fold_consumer(st, 1, B.fc);
   ff.fold_colsum = B.fc.fold_sg;
   HIPCHK(E, gemm(E, EPI_GELU, hi, B.fc.fwg(), T, 4 * d, d, B.fc.fold_b, nullptr, nullptr, st.a16, nullptr, s, -1, 0, &ff));
+  dbg_ck(E, st.a16, (size_t)T * 4 * d * 2, s);
   if (!fold_producer(E, st, 0, T, d, 4 * d, B.ln1, s, &fp)) return fail(E, MVLPT_ERR_STATE, "packed residual stream: MLP down-projection cannot produce the ln_1 statistics");
   fp.rp_hi_in = hi; fp.rp_lo_in = lo; fp.rp_lo_out = lo;
   HIPCHK(E, gemm(E, EPI_RESIDP_LN, st.a16, B.pr.fw(), T, d, 4 * d, B.pr.b, nullptr, nullptr, hi, nullptr, s, -1, 0, &fp));
+  dbg_ck(E, hi, (size_t)T * d * 3, s); dbg_ck(E, fp.ln_part, (size_t)T * fp.ln_ntp * 8, s);
   return 0;
 }
 
@@ -726,6 +739,25 @@ int mvlpt_set_vpt_dropout(void* h, const float* masks, int n_layers, int batch, 
   return 0;
 }
 
+int mvlpt_debug_checksums(void* h, int enable, unsigned long long* host_out, int max_out) {
+  Engine* E = (Engine*)h;
+  if (!E) return MVLPT_ERR_ARG;
+  int n = 0;
+  if (host_out && max_out > 0 && E->dbg_ck) {
+    HIPCHK(E, hipDeviceSynchronize());
+    n = E->dbg_ck_n < max_out ? E->dbg_ck_n : max_out;
+    HIPCHK(E, hipMemcpy(host_out, E->dbg_ck, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  }
+  if (enable && !E->dbg_ck) {
+    void* p = nullptr;
+    HIPCHK(E, hipMalloc(&p, DBG_CK_MAX * sizeof(unsigned long long)));
+    E->owned.push_back(p);
+    E->dbg_ck = (unsigned long long*)p;
+  }
+  E->dbg_ck_on = enable != 0;
+  return n;
+}
+
 int mvlpt_trim(void* h) {
   Engine* E = (Engine*)h;
   if (!E) return MVLPT_ERR_ARG;
@@ -874,7 +906,10 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
   auto vmask = [&](int l) -> const float* { return masks ? masks + (size_t)l * B * n_vpt * dv : nullptr; };
   { ProfScope ps(E, s, PC_GLUE, 0, (double)npatch * E->Kp * 6.0);
     HIPCHK(E, launch_patchify(E->dt, image, image_dtype, patches, B, A.image_resolution, A.patch_size, E->Kp, s)); }
+  if (E->dbg_ck_on) { E->dbg_ck_n = 0; if (E->dbg_ck) (void)hipMemsetAsync(E->dbg_ck, 0, DBG_CK_MAX * sizeof(unsigned long long), s); }
+  dbg_ck(E, patches, (size_t)npatch * E->Kp * 2, s);
   HIPCHK(E, gemm(E, EPI_STORE32, patches, WRef{E->conv_w, 0, 0}, (int)npatch, dv, E->Kp, nullptr, nullptr, nullptr, pe, nullptr, s));
+  dbg_ck(E, pe, (size_t)npatch * dv * 4, s);
   // Packed residual stream (block_fwd_packed): fp16 tower, no prompts, nothing saved, every LayerNorm folded.  assemble_tokens
   // writes the rows in the packed format together with the row statistics of ln_1 of block 0.
   const int nt_d = dv / 128, ntp_d = (nt_d + 1) & ~1;
@@ -886,6 +921,7 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
     ProfScope ps(E, s, PC_GLUE, 0, (double)B * Lv * dv * 7.0);
     HIPCHK(E, launch_assemble_tokens_packed(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, xhi, xlo, st.part[0], ntp_d, B, G2, dv, s));
     st.nt[0] = nt_d; st.ntp[0] = ntp_d;
+    dbg_ck(E, xhi, (size_t)B * Lv * dv * 3, s); dbg_ck(E, st.part[0], (size_t)B * Lv * ntp_d * 8, s);
   } else {
     ProfScope ps(E, s, PC_GLUE, 0, (double)B * Lv * dv * 8.0);
     HIPCHK(E, launch_assemble_tokens(pe, E->cls_emb, E->vpos, E->ln_pre.g, E->ln_pre.b, vpt, n_vpt, st.x[0], B, G2, dv, s, vmask(0)));
@@ -939,6 +975,7 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
     if (packed) fq.fold_colsum = Bk.qkv.fold_sg;       // A = the stream's hi plane, gamma inside the weight
     HIPCHK(E, gemm(E, xs ? EPI_STORE_SPLIT : EPI_STORE16, packed ? xhi : st.h16, packed ? Bk.qkv.fwg() : Bk.qkv.fw(), T, 3 * dv, dv,
                    ln1_ready ? Bk.qkv.fold_b : Bk.qkv.b, nullptr, nullptr, st.qkv[l], nullptr, s, -1, xs, ln1_ready ? &fq : nullptr));
+    dbg_ck(E, st.qkv[l], (size_t)T * 3 * dv * 2 * X, s);
     if (xs) {
       // only the CLS rows of the attention output are produced: the backward (delta = rowsum(dO * O) over EVERY row, with
       // dO = 0 off the CLS rows) must not meet uninitialised memory there
@@ -953,6 +990,7 @@ int mvlpt_image_fwd(void* h, const void* image, int image_dtype, const float* vp
       HIPCHK(E, launch_copy_rows_strided(st.attn[l], E->ac16, B, (size_t)Lv * dv * 2 * X, (size_t)dv * 2 * X, (int)(dv * 2 * X), s));
       if (packed) HIPCHK(E, launch_respk_unpack_rows(xhi, xlo, Lv, E->xc32, B, dv, s));
       else HIPCHK(E, launch_copy_rows_strided(xin, E->xc32, B, (size_t)Lv * dv * 4, (size_t)dv * 4, dv * 4, s)); }
+    dbg_ck(E, E->ac16, (size_t)B * dv * 2 * X, s); dbg_ck(E, E->xc32, (size_t)B * dv * 4, s);
     HIPCHK(E, gemm(E, EPI_RESID32, E->ac16, Bk.o.fw(), B, dv, dv, Bk.o.b, nullptr, E->xc32, xmid, nullptr, s, -1, xs));
     HIPCHK(E, ln_fwd(E, E->dt, xmid, nullptr, 1, Bk.ln2, E->hc16, B, dv, s, xs));
     HIPCHK(E, gemm(E, xs ? EPI_GELU_SPLIT : EPI_GELU, E->hc16, Bk.fc.fw(), B, 4 * dv, dv, Bk.fc.b, nullptr, nullptr, E->gc16, save ? E->uc16 : nullptr, s, -1, xs));
@@ -1323,6 +1361,11 @@ int mvlpt_op_fold_weight(const void* W16, int ld, const float* gamma, void* Wg16
 }
 int mvlpt_op_respk_pack(const float* x, void* hi, uint8_t* lo, float* part, int ntp, int rows, int d, mvlpt_stream_t stream) {
   OPCHK(launch_respk_pack_rows(x, hi, lo, part, ntp, rows, d, (hipStream_t)stream));
+  return 0;
+}
+int mvlpt_op_assemble_packed(const float* patch_emb, const float* cls, const float* pos, const float* ln_g, const float* ln_b, void* hi,
+                             uint8_t* lo, float* part, int ntp, int batch, int grid2, int d, mvlpt_stream_t stream) {
+  OPCHK(launch_assemble_tokens_packed(patch_emb, cls, pos, ln_g, ln_b, hi, lo, part, ntp, batch, grid2, d, (hipStream_t)stream));
   return 0;
 }
 int mvlpt_op_respk_unpack(const void* hi, const uint8_t* lo, int row_mul, float* out, int rows, int d, mvlpt_stream_t stream) {

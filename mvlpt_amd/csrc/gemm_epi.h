@@ -77,10 +77,12 @@ __device__ __forceinline__ void fold_build_coef(const GemmArgs& g, char* xl, cha
 }
 // The consumer side of the folding on one register quad: rstd_r * acc + (-rstd_r * mean_r * colsum + bias2), element by element on
 // the SCALAR fma.  Left to itself hipcc packs the four elements into two v_pk_fma_f32 with op_sel (the row coefficients broadcast
-// into both halves of the pair); in gemm_bt_kernel<f16, EPI_GELU_SPLIT_FOLD, 128, 128, 4, 2, MIXED> that form delivered — only while
-// another stream's kernels shared the SIMDs, in ~40 % of the launches — a wrong LOW element in lanes 48-63 of a few row segments
-// (tools/fold_consumer_repro.py; the same code on scalar fmas: 0 of 360 launches; NOTES round 5).  v_pk_fma_f32 is not faster than
-// two v_fma_f32 on gfx950, so nothing is lost.  (Bit-identical results: both forms are fused.)
+// into both halves of the pair), and on gfx950 that form is a HAZARD the compiler does not pad: straight behind the partial
+// `s_waitcnt lgkmcnt(1)` that releases the coefficient pair, the LOW lane's read of the pair's HIGH register returns 0 in lanes 48-63
+// whenever another wave keeps the matrix pipe busy (round 5: ~40 % of the launches of gemm_bt_kernel<f16, EPI_GELU_SPLIT_FOLD, 128,
+// 128, 4, 2, MIXED> under a concurrent text tower; root cause, micro-reproducer and audit: NOTES_experiments.md round 6,
+// tools/pkfma_hazard.hip, tools/isa_audit.py).  The whole library is now built without packed fp32 instructions (Makefile NOPK);
+// the explicit scalar form stays so that the arithmetic does not depend on that flag.  (Bit-identical results: both forms are fused.)
 __device__ __forceinline__ f32x4 fold_apply(float fa, float fcc, const f32x4& acc, const f32x4& colsum, const f32x4& bias2) {
 #ifdef MVLPT_FOLD_PK      // the round-5 form that failed (debug builds of the reproducer only): 1 as it was; 2 every input complete and
   {                       // 16 wait states old before the arithmetic; 3 the results 8 wait states old before their first use

@@ -154,6 +154,23 @@ hipError_t launch_pack_weight8(const float* w, uint8_t* out8, int rows, int cols
   return hipGetLastError();
 }
 
+// Debug: order-independent 64-bit checksum of a buffer (sum of its 32-bit words), added into *out.  mvlpt_debug_checksums uses it to
+// fingerprint every intermediate of a tower so that two runs can be compared stage by stage without keeping the tensors.
+__global__ __launch_bounds__(256) void checksum_kernel(const uint32_t* __restrict__ p, size_t nwords, unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
+    acc += (unsigned long long)__builtin_nontemporal_load(p + i) * (unsigned long long)((i & 1023) + 1);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+hipError_t launch_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t s) {
+  const size_t n = bytes / 4;
+  if (!n) return hipSuccess;
+  const size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(checksum_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, s, (const uint32_t*)p, n, out);
+  return hipGetLastError();
+}
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s) { return bytes ? hipMemsetAsync(p, 0, bytes, s) : hipSuccess; }
 
 // ------------------------------------------------------------------------------------------------ image side
@@ -610,7 +627,38 @@ __global__ void grad_scale_finish_kernel(float target, float* scale_dev) {
   scale_dev[0] = sc;
   scale_dev[1] = 1.0f / sc;
 }
+// the step's own call (dfeat of the text / image tower: C x e or B x e values, a few hundred KB) as ONE launch of one workgroup:
+// memset + 50-block amax + finish were three launches and ~25 us on the text tower's critical chain
+__global__ __launch_bounds__(1024) void grad_scale_small_kernel(const float* __restrict__ v, int n, float target, float* scale_dev) {
+  __shared__ float part[16];
+  float m = 0.f;
+  for (int i = threadIdx.x * 4; i < n; i += 4096) {
+    if (i + 4 <= n) { const f32x4 q = *(const f32x4*)(v + i); m = fmaxf(fmaxf(m, fmaxf(fabsf(q[0]), fabsf(q[1]))), fmaxf(fabsf(q[2]), fabsf(q[3]))); }
+    else for (int k = i; k < n; ++k) m = fmaxf(m, fabsf(v[k]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // NaN / inf must surface as in the two-stage version (atomicMax on the bit pattern): compare bit patterns of the non-negative values
+    unsigned mb = 0;
+    for (int w = 0; w < 16; ++w) { const unsigned b = __float_as_uint(part[w]); mb = b > mb ? b : mb; }
+    const float mm = __uint_as_float(mb);
+    float sc = 1.0f;
+    if (mm > 0.f && isfinite(mm)) {
+      int e; frexpf(mm, &e);
+      int et; frexpf(target, &et);
+      int k = et - e; k = k > 60 ? 60 : (k < -60 ? -60 : k);
+      sc = ldexpf(1.0f, k);
+    }
+    scale_dev[0] = sc; scale_dev[1] = 1.0f / sc; scale_dev[2] = mm;
+  }
+}
 hipError_t launch_grad_scale(const float* v, size_t n, float target, float* scale_dev, hipStream_t s) {
+  if (n <= (1u << 20) && ((size_t)v & 15) == 0) {
+    hipLaunchKernelGGL(grad_scale_small_kernel, dim3(1), dim3(1024), 0, s, v, (int)n, target, scale_dev);
+    return hipGetLastError();
+  }
   hipError_t e = hipMemsetAsync(scale_dev + 2, 0, sizeof(float), s);
   if (e != hipSuccess) return e;
   const size_t want = (n + 1023) / 1024;

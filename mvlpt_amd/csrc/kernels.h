@@ -243,6 +243,7 @@ hipError_t launch_gather_ctx_grad(const float* dx, const int32_t* ctx_pos, int C
 // scale_dev[0] = 2^k with amax(|v|)*2^k ~ target ; scale_dev[1] = 1/scale_dev[0]
 hipError_t launch_grad_scale(const float* v, size_t n, float target, float* scale_dev, hipStream_t s);
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);
+hipError_t launch_checksum(const void* p, size_t bytes, unsigned long long* out, hipStream_t s);      // debug (mvlpt_debug_checksums)
 // LayerNorm folding: colsum[n] = sum_k W16[n,k] gamma[k], bias2[n] = b[n] + sum_k W16[n,k] beta[k]  (W16 [N, ld] packed weight)
 hipError_t launch_fold_vectors(int dtype, const void* W16, int ld, const float* gamma, const float* beta, const float* b,
                                float* colsum, float* bias2, int N, int K, hipStream_t s);

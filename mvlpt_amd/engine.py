@@ -123,6 +123,14 @@ class Engine:
         sh = (0, 0, 0, 0) if masks is None else tuple(int(v) for v in masks.shape)
         _lib.check(lib.mvlpt_set_vpt_dropout(self.h, _ptr(masks), *sh), self.h, "set_vpt_dropout")
 
+    def debug_checksums(self, enable: bool = True):
+        """mvlpt_debug_checksums: the stage fingerprints of the last image_fwd (list of ints) and the new on / off state."""
+        buf = (C.c_uint64 * 256)()
+        n = lib.mvlpt_debug_checksums(self.h, int(bool(enable)), buf, 256)
+        if n < 0:
+            raise RuntimeError(_lib.last_error(self.h))
+        return [int(buf[i]) for i in range(n)]
+
     def set_ln_fold(self, mode: int, min_rows: int = 4096) -> None:
         """LayerNorm folding (include/mvlpt_hip.h: mvlpt_set_ln_fold): 0 off, 1 image tower, 2 both towers."""
         _lib.check(lib.mvlpt_set_ln_fold(self.h, int(mode), int(min_rows)), self.h, "set_ln_fold")
@@ -559,6 +567,19 @@ def op_respk_pack(x: torch.Tensor, ntp: int = 0):
     lo = torch.empty(rows, d, device=x.device, dtype=torch.int8)
     part = torch.full((rows, ntp, 2), float("nan"), device=x.device, dtype=torch.float32) if ntp else None
     _lib.check(lib.mvlpt_op_respk_pack(_ptr(x.contiguous()), _ptr(hi), _ptr(lo), _ptr(part), ntp, rows, d, _stream()), None, "op_respk_pack")
+    return hi, lo, part
+
+
+def op_assemble_packed(pe: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, g: torch.Tensor, b: torch.Tensor, batch: int, ntp: int = 6):
+    """patch embeddings fp32 [batch * G2, d] -> the packed tower entry: (hi fp16 [batch * (1 + G2), d], lo int8, part [rows, ntp, 2])."""
+    d = pe.shape[1]
+    G2 = pe.shape[0] // batch
+    rows = batch * (1 + G2)
+    hi = torch.empty(rows, d, device=pe.device, dtype=torch.float16)
+    lo = torch.empty(rows, d, device=pe.device, dtype=torch.int8)
+    part = torch.empty(rows, ntp, 2, device=pe.device, dtype=torch.float32)
+    _lib.check(lib.mvlpt_op_assemble_packed(_ptr(pe), _ptr(cls), _ptr(pos), _ptr(g), _ptr(b), _ptr(hi), _ptr(lo), _ptr(part), ntp, batch, G2, d,
+                                            _stream()), None, "op_assemble_packed")
     return hi, lo, part
 
 

@@ -234,7 +234,7 @@ def test_folded_mlp_up_consumer_on_mixed_pairs_is_bit_stable_under_a_concurrent_
 def test_packed_fma_hazard_micro_reproducer_and_the_shipped_form():
     """The instruction-level cause of the round-5 fault (NOTES_experiments.md, round 6): `v_pk_fma_f32 ... op_sel:[0,1,0]` straight behind
     `s_waitcnt lgkmcnt(1)` reads 0 for the broadcast coefficient in the LOW half of lanes 48-63 while another wave keeps the matrix
-    pipe busy.  tools/pkfma_hazard.hip replays 13 instruction forms under a register-only MFMA partner.  The test's requirement is on
+    pipe busy.  tools/pkfma_hazard.hip replays 17 instruction forms under a register-only MFMA partner.  The test's requirement is on
     the SHIPPED form (scalar v_fma_f32 behind the same wait: variant 1) and on the forms one wait state away: no wrong element; the
     failing form's count is printed (on the round-6 boxes: ~4e5 wrong LOW halves of 7.9e9, all in lanes 48-63, none alone)."""
     import os
@@ -253,7 +253,7 @@ def test_packed_fma_hazard_micro_reproducer_and_the_shipped_form():
     for m in re.finditer(r"variant\s+(\d+) .*\n\s+wrong LOW halves[^:]*: (\d+) (\d+) (\d+) (\d+) .*wrong HIGH: (\d+) (\d+) (\d+) (\d+) \| wrong loads: (\d+)", partner):
         v = [int(x) for x in m.groups()]
         counts[v[0]] = (sum(v[1:5]), sum(v[5:9]), v[9], v[1:5])
-    assert len(counts) == 13
+    assert len(counts) == 17
     for v in (1, 2, 3, 4, 5):          # scalar FMAs; a full wait; one or two wait states; one unrelated VALU instruction in between
         assert counts[v][:3] == (0, 0, 0), (v, counts[v])
     assert all(c[2] == 0 for c in counts.values())                               # the LDS reads themselves are never wrong

@@ -1,9 +1,11 @@
 """ISA audit of libmvlpt_hip.so for the gfx950 hazard found in round 6 (NOTES_experiments.md, round 6; tools/pkfma_hazard.hip).
 
-The hazard: a packed fp32 VALU instruction with an op_sel / op_sel_hi source selection (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32)
-issued STRAIGHT behind an `s_waitcnt` that leaves a younger LDS read in flight (lgkmcnt(n), n >= 1) can read 0 instead of the register
-the wait just released, in the LOW half of lanes 48-63, while another wave's MFMA occupies the SIMD.  hipcc (ROCm 7.2) emits exactly that
-sequence whenever it packs a broadcast coefficient that was loaded from LDS.
+The hazard: a packed fp32 VALU instruction whose LOW lane selects the HIGH register of a source pair (op_sel) can read 0 for that source
+in lanes 48-63 when the pair was written immediately before — by an LDS return that a partial `s_waitcnt lgkmcnt(n >= 1)` has just
+released, or by a VALU instruction one slot earlier — while another wave's MFMA occupies the SIMD.  hipcc (ROCm 7.2) emits such
+sequences on its own (the round-5 fold arithmetic; the packed tower entry of round 5's residual stream) and does not pad them.
+The product build therefore compiles WITHOUT packed fp32 instructions (`--packed` checks that); the windowed audit below is what found
+and sized the problem in the older binaries.
 
 The audit extracts every gfx950 code object of the library (clang offload bundles in .hip_fatbin), disassembles it with llvm-objdump and
 reports, per kernel, every packed-fp32 instruction with a non-default op_sel / op_sel_hi whose DISTANCE (in instructions) behind a
@@ -97,6 +99,23 @@ def audit_text(text, distance=2, with_vmcnt=False, all_packed=False):
     return found
 
 
+PACKED_F32 = re.compile(r"^\s*(v_pk_(?:fma|mul|add)_f32|v_pk_mov_b32)\b")
+
+
+def count_packed_fp32(path):
+    """-> {kernel: number of packed fp32 VALU instructions}: the product build has none at all (Makefile: -target-feature -packed-fp32-ops)"""
+    per = {}
+    for obj in code_objects(path):
+        kernel = "?"
+        for line in disassemble(obj).splitlines():
+            lm = LABEL.match(line.strip())
+            if lm and not line.startswith(("\t", " ")):
+                kernel = lm.group(1)
+            elif PACKED_F32.match(line):
+                per[kernel] = per.get(kernel, 0) + 1
+    return per
+
+
 def audit_library(path, distance=2, with_vmcnt=False, all_packed=False):
     found = []
     for obj in code_objects(path):
@@ -110,8 +129,15 @@ def main():
     ap.add_argument("--distance", type=int, default=2, help="flag packed ops fewer than this many instructions behind the partial wait (1 = straight behind)")
     ap.add_argument("--vmcnt", action="store_true", help="also treat a partial vmcnt wait as opening the window")
     ap.add_argument("--all-packed", action="store_true", help="flag packed fp32 ops without op_sel too")
+    ap.add_argument("--packed", action="store_true", help="count EVERY packed fp32 instruction (the product library must have none)")
     ap.add_argument("-v", action="store_true")
     a = ap.parse_args()
+    if a.packed:
+        per = count_packed_fp32(a.lib)
+        print(f"{a.lib}: {sum(per.values())} packed fp32 VALU instruction(s) (v_pk_fma/mul/add_f32, v_pk_mov_b32) in {len(per)} kernel(s)")
+        for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:20 if a.v else 0]:
+            print(f"  {v:5d}  {k[:150]}")
+        return 1 if per else 0
     found = audit_library(a.lib, a.distance, a.vmcnt, a.all_packed)
     per = {}
     for k, w, p, d in found:

@@ -26,7 +26,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-constexpr int NVAR = 13, NCNT = 6;      // counters per (variant, lane group): wrong LOW, wrong HIGH, wrong loads, LOW ~ coefficient 0, LOW NaN, LOW other
+constexpr int NVAR = 17, NCNT = 6;      // counters per (variant, lane group): wrong LOW, wrong HIGH, wrong loads, LOW ~ coefficient 0, LOW NaN, LOW other
 static const char* kVarName[NVAR] = {
   " 0 v_pk_fma_f32 + op_sel straight behind s_waitcnt lgkmcnt(1)            [the round-5 failing form]",
   " 1 scalar v_fma_f32 straight behind the same wait                         [the shipped form]",
@@ -41,6 +41,10 @@ static const char* kVarName[NVAR] = {
   "10 as 0 with GLOBAL loads and s_waitcnt vmcnt(1)",
   "11 as 0, the pair arrives as the first half of a ds_read_b128",
   "12 as 0 with 8 wait states behind lgkmcnt(1): only the second packed op (in place on the younger load) sits straight behind its wait",
+  "13 no load at all: v_pk_mul_f32 writes a pair, v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (halves swapped) reads it in the NEXT instruction",
+  "14 as 13 with one unrelated packed FMA between producer and consumer   [what hipcc emitted in assemble_tokens_kernel<3, packed>]",
+  "15 as 13 with two unrelated VALU instructions between",
+  "16 as 13 with the consumer's halves NOT swapped (plain packed add) in the next instruction",
 };
 
 __device__ __forceinline__ float tab_fa(int row, int it) { return 1.0f + 0.001f * (float)((row * 7 + it) % 97); }
@@ -136,7 +140,23 @@ __global__ __launch_bounds__(256, 2) void probe(unsigned* counters, int iters, c
       else if constexpr (V == 11)
         asm volatile(PRE "ds_read_b128 v[20:23], %10\n\tds_read_b128 v[24:27], %11\n\t"
                      "s_waitcnt lgkmcnt(1)\n\t" T_PKSEL "s_waitcnt lgkmcnt(0)\n\t" R_PKSEL POST OPERANDS);
-      else      // V == 12
+      else if constexpr (V >= 13) {
+        // p = cols01 * cols23 (pair), then r01 = colb01 + swap(p) [13-15] / colb01 + p [16]; r23 the same once more on v[30:31] (second instance)
+        asm volatile(PRE LOADS "s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\t"
+                     "v_pk_mul_f32 v[22:23], v[12:13], v[14:15]\n\t"
+                     ".if %22 == 14\n\tv_pk_fma_f32 v[30:31], v[12:13], v[14:15], v[18:19]\n\t.endif\n\t"
+                     ".if %22 == 15\n\tv_mov_b32 v30, v12\n\tv_mov_b32 v31, v13\n\t.endif\n\t"
+                     ".if %22 == 16\n\tv_pk_add_f32 v[28:29], v[16:17], v[22:23]\n\t.else\n\tv_pk_add_f32 v[28:29], v[16:17], v[22:23] op_sel:[0,1] op_sel_hi:[1,0]\n\t.endif\n\t"
+                     "s_nop 7\n\t"
+                     "v_pk_mul_f32 v[22:23], v[14:15], v[12:13]\n\t"
+                     ".if %22 == 14\n\tv_pk_fma_f32 v[20:21], v[12:13], v[14:15], v[18:19]\n\t.endif\n\t"
+                     ".if %22 == 15\n\tv_mov_b32 v20, v12\n\tv_mov_b32 v21, v13\n\t.endif\n\t"
+                     ".if %22 == 16\n\tv_pk_add_f32 v[30:31], v[18:19], v[22:23]\n\t.else\n\tv_pk_add_f32 v[30:31], v[18:19], v[22:23] op_sel:[0,1] op_sel_hi:[1,0]\n\t.endif\n\t"
+                     "s_nop 7\n\tds_read_b64 v[20:21], %10\n\t" POST
+                     : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                     : "v"(tab_addr), "v"(scr_addr), "v"(cols[0]), "v"(cols[1]), "v"(cols[2]), "v"(cols[3]), "v"(colb[0]), "v"(colb[1]), "v"(colb[2]), "v"(colb[3]), "v"(gtab), "v"(gscr), "n"(V)
+                     : "memory", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");
+      } else      // V == 12
         asm volatile(PRE LOADS "s_waitcnt lgkmcnt(1)\n\ts_nop 7\n\t" T_PKSEL "s_nop 7\n\ts_waitcnt lgkmcnt(0)\n\t" R_PKSEL POST OPERANDS);
       // the loads themselves (read back long after every wait) must equal what was written
       float ea0 = tab_fa(trow, it), ea1 = tab_fcc(trow, it);
@@ -147,6 +167,11 @@ __global__ __launch_bounds__(256, 2) void probe(unsigned* counters, int iters, c
       float x[4], z[4];      // expected results, and the results with the broadcast coefficient of the FIRST op read as zero
       const float rr[4] = {r0, r1, r2, r3};
       for (int e = 0; e < 4; ++e) {
+        if (V >= 13) {      // r[e]: colb[e] + the product the (possibly swapped) half selects; "coefficient read as 0" = colb[e] + 0
+          const float pr[2] = {__fmul_rn(cols[0], cols[2]), __fmul_rn(cols[1], cols[3])};      // (no contraction into an fma)
+          const int sel = V == 16 ? (e & 1) : 1 - (e & 1);
+          x[e] = __fadd_rn(colb[e], pr[sel]); z[e] = colb[e] + 0.0f;
+        } else
         if (V == 6) { x[e] = fmaf(eb[e], cols[e], fmaf(cols[e], (e & 1) ? ea1 : ea0, colb[e])); z[e] = fmaf(eb[e], cols[e], fmaf(cols[e], 0.0f, colb[e])); }
         else if (V == 7) { x[e] = fmaf(eb[e], cols[e], fmaf(ea0, cols[e], colb[e])); z[e] = fmaf(eb[e], cols[e], fmaf(0.0f, cols[e], colb[e])); }
         else if (V == 8) { x[e] = fmaf(ea0, eb[e], cols[e] * ea1); z[e] = fmaf(ea0, eb[e], cols[e] * 0.0f); }
