@@ -481,7 +481,7 @@ def main():
                        "loop": "TrainerX.run_epoch = the plain Dassl loop `for batch in train_loader_x: forward_backward(batch)`; the one-batch look-ahead comes from the loader (LookAheadLoader, installed by MVLPT.build_data_loader)", "step_pipelining": bool(pipeline),
                        "grad_precision": args.grad_precision,
                        "layernorm_folding": {"0": "off", "1": "image tower", "2": "both towers"}.get(os.environ.get("MVLPT_LN_FOLD", "2"), "both towers"),
-                       "residual_stream": "packed fp16 + byte (image tower without prompts / backward)" if os.environ.get("MVLPT_RESID_PACKED", "0") not in ("", "0") else "fp32",
+                       "residual_stream": "packed fp16 + byte (image tower without prompts / backward)" if (os.environ.get("MVLPT_RESID_PACKED", "1") not in ("", "0") and n_vpt == 0 and args.dtype == "fp16") else "fp32",
                        "cu_partition": ({"text_tower_cus": trainer.model.text_cus, "image_tower_cus": eng_cus - trainer.model.text_cus}
                                         if trainer.model.text_cus else "none (towers share every compute unit)"),
                        "per_gpu_batch": args.batch, "global_batch": B_global, "parallelism": f"dp{world}",

@@ -62,13 +62,14 @@ int mvlpt_set_precision(void* handle, int mode);
  * stand-alone LayerNorm pass over the residual stream disappears.  mode 0: off, 1: image tower, 2: both towers (default;
  * environment MVLPT_LN_FOLD); towers with fewer than `min_rows` token rows (default 4096) keep the stand-alone kernel. */
 int mvlpt_set_ln_fold(void* handle, int mode, int min_rows);
-/* Packed residual stream (OFF by default, experimental; environment MVLPT_RESID_PACKED = 1): an fp16 image tower that has no prompt rows and keeps
- * nothing for a backward (the CoOp configurations, BASELINE configs[0..1]; clip/model.py:185-188 `x = x + ...`) carries the
- * residual stream as hi = round16(x) + one byte with the next 8 bits of x instead of fp32, and hi is at the same time the
+/* Packed residual stream (ON by default since round 6; environment MVLPT_RESID_PACKED = 0 switches it off): an fp16 image tower that has
+ * no prompt rows and keeps nothing for a backward (the CoOp configurations, BASELINE configs[0..1]; clip/model.py:185-188 `x = x + ...`)
+ * carries the residual stream as hi = round16(x) + one byte with the next 8 bits of x instead of fp32, and hi is at the same time the
  * 16-bit operand of the GEMM behind every LayerNorm (its gamma folded into the frozen weight): 6 instead of 10 bytes of memory
- * traffic per element and residual update, x carried to 2^-20; image tower alone -1.7 %.  Parity-green and bit-stable by itself, but with the
- * text tower running on another stream ~1 tower in 1 000 - 6 000 returns ONE image's features 1e-3 off (cause not found; the fp32 stream:
- * 0 in 59 200) — hence not the default.  0: the fp32 stream everywhere. */
+ * traffic per element and residual update, x carried to 2^-20 (|x| saturates at 65504); image tower alone -1.7 %, headline step -0.9 %.
+ * Round 5 kept it off because ~1 tower in 1 000 - 6 000 returned ONE image 1e-3 off under a concurrent text tower: that was the gfx950
+ * packed-fp32 hazard in the tower entry kernel (NOTES_experiments.md round 6), gone since the library is built without packed fp32
+ * instructions: 0 in 20 000 towers.  0: the fp32 stream everywhere. */
 int mvlpt_set_resid_packed(void* handle, int on);
 /* `vpt_dropout` of the reference (trainers/mvlpt.py:165, 424 and :77): the visual prompt rows are expanded over the batch and THEN
  * dropped out, so every image has its own mask.  masks = fp32 [n_layers, B, n_vpt, width] on the device, 0 or 1 / (1 - p): layer 0

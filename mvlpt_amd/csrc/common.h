@@ -102,7 +102,8 @@ __device__ __forceinline__ float join_lo8(T hi, uint32_t lo8_word, int byte) {
 // Packed residual stream (fp16 towers without a gradient): a fp32 value x travels as hi = round16(x) — which is at
 // the same time the 16-bit A operand of the GEMM behind the next LayerNorm — plus ONE byte that carries the next 8 bits of x:
 // for a normal fp16 `hi`, float(hi) has 13 zero mantissa bits and the fp32 bit patterns differ by d = bits(x) - bits(float(hi)),
-// |d| <= 2^12 (integer arithmetic on the bit patterns handles the mantissa / exponent carries and both signs);
+// |d| <= 2^12 (integer arithmetic on the bit patterns handles the mantissa / exponent carries and both signs; x is saturated to the
+// fp16 range first, so hi is finite for every finite x);
 // lo = clamp(d >> 5, -128, 127) as int8 and x' = bits(float(hi)) + (lo << 5) is x to 2^-9 of an fp16 ulp (~2^-20 relative; fp16
 // subnormals: to 2^-25 absolute).  6 bytes per element and residual update (3 read + 3 written) instead of 10
 // (fp32 read + fp32 written + the 16-bit operand copy).
@@ -110,7 +111,7 @@ __device__ __forceinline__ uint32_t respk_split4(f32x4 v, f16x4& hi) {
   int q[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    float x = v[e];
+    float x = __builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);      // saturate: hi must stay finite (it is the next GEMM's A operand)
     asm volatile("" : "+v"(x));      // (see split16: one rounding of the materialised value)
     hi[e] = (f16)x;
     const int d = __builtin_bit_cast(int, x) - __builtin_bit_cast(int, (float)hi[e]);

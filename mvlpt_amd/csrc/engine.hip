@@ -150,11 +150,13 @@ struct Engine {
   int dt = DT_F16;
   int prec_mode = MVLPT_PREC_SPLIT_GRAD;
   int fold_mode = 2;    // LayerNorm folding: 0 off, 1 image tower, 2 both towers (MVLPT_LN_FOLD, mvlpt_set_ln_fold)
-  int fold_min_rows = 4096;   // towers with fewer token rows keep the stand-alone LayerNorm (a handful of tiles: little to win — 2 % at 1 600 rows — and the small-tile consumer geometries are the least exercised: NOTES, round 5)
+  int fold_min_rows = 1024;   // towers with fewer token rows keep the stand-alone LayerNorm (a handful of tiles: nothing to win).  4096 until round 6: the small-tile
+                              // consumer geometries were where the packed-fp32 hazard first showed (NOTES round 6); cfg1 (1 600 image rows): -1.5 %
   bool fold_ready = false;
   // packed residual stream: the fp16 image tower without prompts and without a backward carries x as hi (fp16, at the
   // same time the A operand behind every LayerNorm) + one byte instead of fp32 + a 16-bit copy.  MVLPT_RESID_PACKED / mvlpt_set_resid_packed
-  int resid_packed = 0;      // off by default: one image in ~3 000 towers comes out 1e-3 off while the text tower runs on another stream (NOTES round 5)
+  int resid_packed = 1;      // on (round 6): the rare 1e-3 glitch of round 5 was the packed-fp32 hazard in the tower entry, gone with the NOPK build
+                             // (0 / 20 000 towers under a concurrent text tower, profiles/r06_packed_stream_determinism.txt); MVLPT_RESID_PACKED=0: fp32 stream
   // mvlpt_set_vpt_dropout: [layers, B, n_vpt, d] masks of the visual prompt rows for the NEXT image_fwd (one-shot: the forward
   // validates the geometry, takes the setting over as v_mask — what ITS backward uses — and clears it, so a stale pointer never
   // reaches another forward or another user of the engine)

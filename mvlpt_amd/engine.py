@@ -131,7 +131,7 @@ class Engine:
             raise RuntimeError(_lib.last_error(self.h))
         return [int(buf[i]) for i in range(n)]
 
-    def set_ln_fold(self, mode: int, min_rows: int = 4096) -> None:
+    def set_ln_fold(self, mode: int, min_rows: int = 1024) -> None:
         """LayerNorm folding (include/mvlpt_hip.h: mvlpt_set_ln_fold): 0 off, 1 image tower, 2 both towers."""
         _lib.check(lib.mvlpt_set_ln_fold(self.h, int(mode), int(min_rows)), self.h, "set_ln_fold")
 

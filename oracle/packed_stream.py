@@ -5,6 +5,7 @@ include/mvlpt_hip.h mvlpt_op_respk_* / mvlpt_op_gemm_residp) and of the arithmet
 The reference keeps the residual stream `x = x + attention(ln_1(x))`, `x = x + mlp(ln_2(x))` (clip/model.py:185-188) in the model's
 dtype; the engine's gradient-free fp16 image tower carries it as
 
+    x  = clamp(x, -65504, 65504)                     a fp16 tower cannot carry more: hi stays finite (NaN stays NaN)
     hi = round16(x)                                  fp16 — at the same time the 16-bit operand of the GEMM behind the LayerNorm
     lo = clamp((bits(x) - bits(float(hi))) >> 5, -128, 127)  int8 — the next 8 bits of x (arithmetic shift; bits() = the fp32 pattern)
     x' = bits(float(hi)) + (lo << 5)                 the value a later kernel reads back
@@ -16,7 +17,7 @@ import numpy as np
 
 def pack(x: np.ndarray):
     """fp32 array -> (hi float16, lo int8)."""
-    x = np.ascontiguousarray(x, dtype=np.float32)
+    x = np.clip(np.ascontiguousarray(x, dtype=np.float32), np.float32(-65504.0), np.float32(65504.0))      # (np.clip keeps NaN)
     hi = x.astype(np.float16)
     d = x.view(np.int32).astype(np.int64) - hi.astype(np.float32).view(np.int32).astype(np.int64)
     return hi, np.clip(d >> 5, -128, 127).astype(np.int8)      # (only fp16 subnormals and round-to-even ties ever clamp)

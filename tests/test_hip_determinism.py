@@ -179,7 +179,7 @@ def test_small_split_image_tower_with_folding_forced_on_is_bit_stable_under_a_co
                 assert torch.equal(f, f0), f"image features changed under a concurrent text tower (iteration {it})"
                 assert torch.equal(a, a0) and torch.equal(b, b0), f"visual-prompt gradients changed (iteration {it})"
     finally:
-        eng.set_ln_fold(2, 4096)
+        eng.set_ln_fold(2, 1024)
 
 
 def test_folded_mlp_up_consumer_on_mixed_pairs_is_bit_stable_under_a_concurrent_text_tower():

@@ -161,7 +161,7 @@ def test_full_size_fixtures_with_folding_forced_on(arch_name, name):
         run_case(case, model, image, TOL_FP16, GRAD_TOL_FP16)
         _check_inference(case, _inference_logits(case, build_model(case, clip, res, pre, suf), image), name)
     finally:
-        clip.engine.set_ln_fold(2, 4096)
+        clip.engine.set_ln_fold(2, 1024)
 
 
 @pytest.mark.parametrize("mean_over_std,outlier,tol", [(10.0, 300.0, 3e-3), (100.0, 2000.0, 1.2e-2)])

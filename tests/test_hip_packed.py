@@ -57,6 +57,19 @@ def test_pack_unpack_bit_exact(rows, d):
         assert np.array_equal(z.cpu().numpy(), P.unpack(rh, rl)[::5])
 
 
+def test_pack_saturates_values_beyond_the_fp16_range():
+    """|x| > 65504: hi stays finite, the stored value is +-65504, bit for bit as oracle/packed_stream.py states."""
+    E = _E()
+    x = torch.zeros(4, 512)
+    x[0, :8] = torch.tensor([7e4, -7e4, 1e9, -3e38, 65504.0, 65519.9, float("inf"), float("-inf")])
+    x[1] = torch.randn(512) * 3e4
+    hi, lo, _ = E.op_respk_pack(x.cuda(), ntp=8)
+    rh, rl = P.pack(x.numpy())
+    assert np.array_equal(hi.cpu().numpy(), rh) and np.array_equal(lo.cpu().numpy(), rl)
+    assert bool(torch.isfinite(hi.float()).all())
+    assert np.array_equal(E.op_respk_unpack(hi, lo).cpu().numpy(), P.unpack(rh, rl))
+
+
 def test_fold_weight_bit_exact():
     E = _E()
     g = torch.Generator().manual_seed(1)
@@ -195,7 +208,7 @@ def test_image_features_packed_vs_fp32_stream_vs_oracle(arch_name, B):
         eng.set_resid_packed(False)
         f_plain = eng.image_fwd(image.cuda().half()).float().cpu()
     finally:
-        eng.set_resid_packed(False)
+        eng.set_resid_packed(True)
     assert torch.equal(f_packed, f_again)
     nref = min(B, 6)
     torch.set_num_threads(8)
@@ -225,5 +238,5 @@ def test_coop_fixtures_with_the_packed_tower(arch_name, name, packed):
         run_case(case, model, image, TOL_FP16, GRAD_TOL_FP16)
         _check_inference(case, _inference_logits(case, build_model(case, clip, res, pre, suf), image), name)
     finally:
-        clip.engine.set_ln_fold(2, 4096)
-        clip.engine.set_resid_packed(False)
+        clip.engine.set_ln_fold(2, 1024)
+        clip.engine.set_resid_packed(True)

@@ -72,3 +72,14 @@ def test_fold_weight_matches_layernorm_algebra():
     want = ((x - mean) * rstd * g + b) @ W.astype(np.float64).T
     got = rstd * (x.astype(np.float64) @ Wg.astype(np.float64).T - mean * cs) + W.astype(np.float64) @ b
     assert np.abs(got - want).max() < 2e-3 * np.abs(want).max()
+
+
+def test_values_beyond_the_fp16_range_saturate_instead_of_becoming_infinite():
+    """|x| > 65504 used to give hi = inf and a reconstructed 3.4e38; the format saturates x first (a fp16 tower cannot carry
+    such a value anyway: it is the next GEMM's A operand)."""
+    x = np.array([7e4, -7e4, 1e9, -3e38, 65504.0, 65519.9, np.inf, -np.inf], dtype=np.float32)
+    hi, lo = P.pack(x)
+    assert np.all(np.isfinite(hi.astype(np.float32))) and np.all(np.abs(hi.astype(np.float32)) == 65504.0)
+    assert np.array_equal(P.unpack(hi, lo), np.sign(x) * np.float32(65504.0))
+    hi, lo = P.pack(np.array([np.nan], dtype=np.float32))
+    assert np.isnan(hi[0])
