@@ -557,7 +557,10 @@ def main():
                     continue
                 Mq, Nq, Kq, eq, sq, fq = (int(x) for x in m.groups())
                 avg_us = 1e3 * v["ms"] / v["launches"]
-                per_kernel.append({"name": names.get((Mq, Nq, Kq), "other") + (" (dX)" if eq in (3, 6) else ""), "M": Mq, "N": Nq, "K": Kq, "epilogue": eq,
+                epi_names = {0: "store16", 1: "gelu", 2: "resid32", 3: "gelu_bwd", 4: "store32", 5: "gelu_split", 6: "gelu_bwd_split", 7: "store_split",
+                             8: "resid32 + LayerNorm producer", 13: "packed residual + LayerNorm producer"}
+                per_kernel.append({"name": names.get((Mq, Nq, Kq), "text tower / head" if Mq != Ti else "image tower, other"), "M": Mq, "N": Nq, "K": Kq,
+                                   "epilogue": epi_names.get(eq, str(eq)),
                                    "operands": {0: "single", 1: "16-bit pair", 2: "mixed pair"}[sq], "ln_fold_consumer": bool(fq),
                                    "launches_per_step": round(v["launches"] / n_sampled, 2), "avg_us": round(avg_us, 1),
                                    "tflops": round(2.0 * Mq * Nq * Kq / avg_us / 1e6, 1),

@@ -15,6 +15,7 @@
 // hardware transpose read ds_read_b64_tr_b16 (and so do the backward kernels for K^T, Q^T, dO^T): no transposed
 // copies are ever staged.  All LDS images are filled by LDS-DMA; per-wave Q/K/V/dO fragments that are used as B
 // operands are fetched from global memory once, before the DMA wait.
+#include <hip/hip_ext.h>
 #include "attn_common.h"
 
 namespace mvlpt {
@@ -631,13 +632,14 @@ hipError_t launch_attn_bwd_cls(int dtype, const void* qkv, const void* o_cls, co
 }
 
 // ======================================================================================= launchers
+static thread_local hipEvent_t t_ev_a = nullptr, t_ev_b = nullptr;      // launch_attn_fwd's optional dispatch events
 template <typename T, int NKT, bool CAUSAL>
 static hipError_t fwd_t(const AttnArgs& a, hipStream_t s) {
   constexpr int LP = NKT * 16;
   constexpr int lds = 2 * LP * 128;
   static bool set = false;
   if (!set) { hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-  hipLaunchKernelGGL((attn_fwd_kernel<T, NKT, CAUSAL>), dim3(a.N * a.H), dim3(256), lds, s, a);
+  hipExtLaunchKernelGGL((attn_fwd_kernel<T, NKT, CAUSAL>), dim3(a.N * a.H), dim3(256), lds, s, t_ev_a, t_ev_b, 0, a);
   return hipGetLastError();
 }
 template <typename T, int NKT, bool CAUSAL>
@@ -701,7 +703,8 @@ static bool use_stream(int L, bool bwd) {
   return L > 256;
 }
 
-hipError_t launch_attn_fwd(int dtype, const AttnArgs& a_, hipStream_t s) {
+hipError_t launch_attn_fwd(int dtype, const AttnArgs& a_, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  t_ev_a = ea; t_ev_b = eb;
   // bit 0: non-temporal K/V staging (one workgroup reads them once), bit 1: non-temporal output stores  (+0.5 % on the step)
   static const int flags = [] { const char* e = getenv("MVLPT_ATTN_FLAGS"); return e ? atoi(e) : 3; }();
   AttnArgs a = a_;
@@ -720,8 +723,8 @@ hipError_t launch_attn_fwd(int dtype, const AttnArgs& a_, hipStream_t s) {
         hipFuncSetAttribute((const void*)attn_fwdp_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
         set = true;
       }
-      if (dtype == DT_F16) hipLaunchKernelGGL((attn_fwdp_kernel<f16>), dim3(cus), dim3(PNW * 64), PLDS, s, a, total);
-      else hipLaunchKernelGGL((attn_fwdp_kernel<bf16>), dim3(cus), dim3(PNW * 64), PLDS, s, a, total);
+      if (dtype == DT_F16) hipExtLaunchKernelGGL((attn_fwdp_kernel<f16>), dim3(cus), dim3(PNW * 64), PLDS, s, ea, eb, 0, a, total);
+      else hipExtLaunchKernelGGL((attn_fwdp_kernel<bf16>), dim3(cus), dim3(PNW * 64), PLDS, s, ea, eb, 0, a, total);
       return hipGetLastError();
     }
   }

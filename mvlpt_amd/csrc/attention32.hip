@@ -31,8 +31,11 @@ namespace mvlpt {
 constexpr int ATR_MAX = 256;
 #define MVLPT_ATR(p) do { if (a.trace && blockIdx.x == 1024 && lane == 0 && atr_n < ATR_MAX) \
     a.trace[wave * ATR_MAX + atr_n++] = ((long long)(p) << 56) | ((long long)__builtin_amdgcn_s_memtime() & 0xffffffffffffffLL); } while (0)
+#define MVLPT_ATRB(p) do { if (a.trace && blockIdx.x == 5 && blockIdx.y == (gridDim.y >> 1) && lane == 0 && atr_n < ATR_MAX) \
+    a.trace[wave * ATR_MAX + atr_n++] = ((long long)(p) << 56) | ((long long)__builtin_amdgcn_s_memtime() & 0xffffffffffffffLL); } while (0)
 #else
 #define MVLPT_ATR(p) do { } while (0)
+#define MVLPT_ATRB(p) do { } while (0)
 #endif
 
 namespace {
@@ -861,6 +864,10 @@ __global__ __launch_bounds__(RNW * 64) void attn32r_bwd_kernel(Attn32BwdArgs a) 
   const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d, gld = 2 * (size_t)d;
   const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
   const T* gbase = (const T*)a.dout_split + (size_t)n * L * gld + h * 64;
+#ifdef MVLPT_ATTN_TRACE
+  int atr_n = 0;
+#endif
+  MVLPT_ATRB(20);
   stage_res<T>(I0h, I0l, base + d, lo, ld, L, wave, lane);          // K
   stage_res<T>(I1h, I1l, base + 2 * d, lo, ld, L, wave, lane);      // V
   const size_t stat0 = ((size_t)n * a.H + h) * L;
@@ -882,8 +889,10 @@ __global__ __launch_bounds__(RNW * 64) void attn32r_bwd_kernel(Attn32BwdArgs a) 
     nlse[o] = -a.lse[stat0 + rc] * LOG2E;
     if (fg == 0 && row < RROWS) { nlse_s[row] = nlse[o]; del_s[row] = dl[o]; }
   }
+  MVLPT_ATRB(21);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  MVLPT_ATRB(22);
   // ---- phase A: own query tiles -> dQ
 #pragma unroll
   for (int o = 0; o < 2; ++o) {
@@ -893,6 +902,7 @@ __global__ __launch_bounds__(RNW * 64) void attn32r_bwd_kernel(Attn32BwdArgs a) 
     v8 Qh[2], Ql[2], Gh[2], Gl[2];
     load_own_pair<T>(Qh, Ql, base + (size_t)rc * ld, lo, fg);
     load_own_pair<T>(Gh, Gl, gbase + (size_t)rc * gld, d, fg);
+    MVLPT_ATRB(23);
     f32x4 dS[RNT];
 #pragma unroll
     for (int kt = 0; kt < RNT; ++kt) {
@@ -908,21 +918,27 @@ __global__ __launch_bounds__(RNW * 64) void attn32r_bwd_kernel(Attn32BwdArgs a) 
         }
       }
     }
+    MVLPT_ATRB(24);
     f32x4 dQ[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dQ[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     accum_res3<T>(dQ, I0h, I0l, dS, 0, nt, fr, fg);
+    MVLPT_ATRB(25);
     if (row < L) {
       T* orow = (T*)a.dqkv_split + ((size_t)n * L + row) * ld + h * 64;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) store_pair4_m<T>(orow + 16 * dt + 4 * fg, lo, h * 64 + 16 * dt + 4 * fg, dQ[dt] * SCALE, a.lo8);
     }
+    MVLPT_ATRB(26);
   }
   __syncthreads();
+  MVLPT_ATRB(27);
   stage_res<T>(I0h, I0l, base, lo, ld, L, wave, lane);              // Q
   stage_res<T>(I1h, I1l, gbase, d, gld, L, wave, lane);             // dO
+  MVLPT_ATRB(28);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  MVLPT_ATRB(29);
   // ---- phase B: own key tiles -> dK, dV
 #pragma unroll
   for (int o = 0; o < 2; ++o) {
@@ -932,6 +948,7 @@ __global__ __launch_bounds__(RNW * 64) void attn32r_bwd_kernel(Attn32BwdArgs a) 
     v8 Kh[2], Kl[2], Vh[2], Vl[2];
     load_own_pair<T>(Kh, Kl, base + d + (size_t)rc * ld, lo, fg);
     load_own_pair<T>(Vh, Vl, base + 2 * d + (size_t)rc * ld, lo, fg);
+    MVLPT_ATRB(30);
     f32x4 P[RNT], dS[RNT];
 #pragma unroll
     for (int qt = 0; qt < RNT; ++qt) {
@@ -949,11 +966,14 @@ __global__ __launch_bounds__(RNW * 64) void attn32r_bwd_kernel(Attn32BwdArgs a) 
         }
       }
     }
+    MVLPT_ATRB(31);
     f32x4 dK[4], dV[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dK[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     accum_res3<T>(dV, I1h, I1l, P, 0, nt, fr, fg);
+    MVLPT_ATRB(32);
     accum_res3<T>(dK, I0h, I0l, dS, 0, nt, fr, fg);
+    MVLPT_ATRB(33);
     if (row < L) {
       T* orow = (T*)a.dqkv_split + ((size_t)n * L + row) * ld + h * 64;
 #pragma unroll
@@ -962,7 +982,9 @@ __global__ __launch_bounds__(RNW * 64) void attn32r_bwd_kernel(Attn32BwdArgs a) 
         store_pair4_m<T>(orow + 2 * d + 16 * dt + 4 * fg, lo, 2 * d + h * 64 + 16 * dt + 4 * fg, dV[dt], a.lo8);
       }
     }
+    MVLPT_ATRB(34);
   }
+  MVLPT_ATRB(35);
 }
 // ------------------------------------------------------------------------------------------------ resident + persistent
 // The resident forward above leaves its staging exposed: one workgroup per CU (104 KiB), so nothing overlaps a head's 104 KiB

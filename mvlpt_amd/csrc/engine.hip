@@ -140,9 +140,9 @@ struct TowerState {
 };
 constexpr int FOLD_NTP = 8;              // slots per row the buffers are sized for (gemm.hip: FOLD_MAX_NTP)
 
-enum ProfClass { PC_GEMM = 0, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD, PC_GLUE, PC_HEAD, PC_COUNT };
+enum ProfClass { PC_GEMM = 0, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD, PC_GLUE, PC_HEAD, PC_ATTN_FWD_IMG, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {"gemm_bt", "attention_fwd", "attention_bwd", "layernorm_fwd", "layernorm_bwd",
-                                           "glue", "head_logits_ce"};
+                                           "glue", "head_logits_ce", "attention_fwd_image"};
 struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes, flops_exec; int M = 0, N = 0, K = 0, epi = -1, split = 0, fold = 0; };
 
 struct Engine {
@@ -223,6 +223,21 @@ constexpr int DBG_CK_MAX = 256;
 static void dbg_ck(Engine* E, const void* p, size_t bytes, hipStream_t s) {
   if (!E->dbg_ck_on || !E->dbg_ck || E->dbg_ck_n >= DBG_CK_MAX) return;
   (void)launch_checksum(p, bytes, E->dbg_ck + E->dbg_ck_n++, s);
+}
+
+// the single-operand attention forward (the headline's image tower), timed like the GEMMs by its own dispatch timestamps whenever
+// profiling is on (class "attention_fwd_image": bench.py's roofline.image_attention_fwd)
+static hipError_t attn_fwd_timed(Engine* E, const AttnArgs& a, double flops, double bytes, hipStream_t s) {
+  hipEvent_t ea = nullptr, eb = nullptr;
+  if (E && E->prof_on && !E->prof_all) {
+    if (E->ev_used + 2 > E->ev_pool.size() && E->ev_pool.size() < 65536)
+      for (int i = 0; i < 512; ++i) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) break; E->ev_pool.push_back(ev); }
+    if (E->ev_used + 2 <= E->ev_pool.size()) {
+      ea = E->ev_pool[E->ev_used++]; eb = E->ev_pool[E->ev_used++];
+      E->prof.push_back(ProfRec{PC_ATTN_FWD_IMG, ea, eb, flops, bytes, flops});
+    }
+  }
+  return launch_attn_fwd(E->dt, a, s, ea, eb);
 }
 
 // ------------------------------------------------------------------------------------------------ kernel wrappers
@@ -431,7 +446,7 @@ int block_fwd(Engine* E, const TowerW& W, TowerState& st, int l, hipStream_t s, 
     AttnArgs a{st.qkv[l], st.attn[l], st.saved ? st.lse[l] : nullptr, st.N, st.L, st.H, st.causal ? 1 : 0};
     const double fl = 4.0 * st.L * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0);
     ProfScope ps(E, s, PC_ATTN_FWD, fl, (double)T * d * 2.0 * 4.0);
-    HIPCHK(E, launch_attn_fwd(E->dt, a, s));
+    HIPCHK(E, attn_fwd_timed(E, a, fl, (double)T * d * 2.0 * 4.0, s));
   }
   const bool p2 = fold_producer(E, st, 1, T, d, d, B.ln2, s, &fo);
   HIPCHK(E, gemm(E, p2 ? EPI_RESID32_LN : EPI_RESID32, st.attn[l], B.o.fw(), T, d, d, B.o.b, nullptr, xin, xmid, nullptr, s, -1, 0, p2 ? &fo : nullptr));
@@ -462,7 +477,7 @@ int block_fwd_packed(Engine* E, const TowerW& W, TowerState& st, int l, hipStrea
     AttnArgs a{st.qkv[l], st.attn[l], nullptr, st.N, st.L, st.H, st.causal ? 1 : 0};
     const double fl = 4.0 * st.L * st.L * 64.0 * st.N * st.H * (st.causal ? 0.5 : 1.0);
     ProfScope ps(E, s, PC_ATTN_FWD, fl, (double)T * d * 2.0 * 4.0);
-    HIPCHK(E, launch_attn_fwd(E->dt, a, s));
+    HIPCHK(E, attn_fwd_timed(E, a, fl, (double)T * d * 2.0 * 4.0, s));
   }
   dbg_ck(E, st.attn[l], (size_t)T * d * 2, s);
   if (!fold_producer(E, st, 1, T, d, d, B.ln2, s, &fo)) return fail(E, MVLPT_ERR_STATE, "packed residual stream: out-projection cannot produce the ln_2 statistics");
@@ -1458,7 +1473,22 @@ int mvlpt_op_attention32_fwd(int dtype, const void* qkv, void* out, float* lse, 
 int mvlpt_op_attention32_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
                              void* dqkv, int N, int L, int H, int causal, mvlpt_stream_t stream) {
   Attn32BwdArgs a{qkv, out, dout, lse, delta, dqkv, N, L, H, causal};
+#ifdef MVLPT_ATTN_TRACE
+  const char* path = getenv("MVLPT_ATTN_TRACE_FILE");
+  long long* tr = nullptr;
+  const size_t tr_bytes = 8 * 256 * sizeof(long long);
+  if (path) { OPCHK(hipMalloc(&tr, tr_bytes)); OPCHK(hipMemsetAsync(tr, 0, tr_bytes, (hipStream_t)stream)); a.trace = tr; }
+#endif
   OPCHK(launch_attn32_bwd(dtype, a, (hipStream_t)stream));
+#ifdef MVLPT_ATTN_TRACE
+  if (path) {
+    std::vector<long long> hbuf(8 * 256);
+    OPCHK(hipStreamSynchronize((hipStream_t)stream));
+    OPCHK(hipMemcpy(hbuf.data(), tr, tr_bytes, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(path, "wb")) { fwrite(hbuf.data(), 1, tr_bytes, f); fclose(f); }
+    (void)hipFree(tr);
+  }
+#endif
   return 0;
 }
 int mvlpt_op_layernorm_fwd(int out_dtype, const float* x, const float* gamma, const float* beta, void* y, int rows, int d,

@@ -655,7 +655,7 @@ __global__ __launch_bounds__(1024) void grad_scale_small_kernel(const float* __r
   }
 }
 hipError_t launch_grad_scale(const float* v, size_t n, float target, float* scale_dev, hipStream_t s) {
-  if (n <= (1u << 20) && ((size_t)v & 15) == 0) {
+  if (n <= (1u << 17) && ((size_t)v & 15) == 0) {      // (C x e, B x e of the step; the load-time calls on whole weight matrices take the wide path)
     hipLaunchKernelGGL(grad_scale_small_kernel, dim3(1), dim3(1024), 0, s, v, (int)n, target, scale_dev);
     return hipGetLastError();
   }

@@ -146,7 +146,8 @@ struct AttnArgs {
   int q_rows = 0;   // > 0: only queries 0..q_rows-1 of every sequence are computed (last layer: only CLS is consumed)
   int flags = 0;    // experiment bits: 1 = non-temporal K/V staging, 2 = non-temporal output stores
 };
-hipError_t launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s);
+// ea / eb (optional): start / stop events of the kernel's own dispatch (hipExtLaunchKernelGGL), for mvlpt_profile_* — resident kernels only
+hipError_t launch_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 struct AttnBwdArgs {
   const void* qkv; const void* out; const void* dout; const float* lse;
   float* delta /*[N*H*L] scratch*/; void* dqkv /*[N*L,3d]*/;
@@ -182,6 +183,9 @@ struct Attn32BwdArgs {
   float* delta /*[N*H*L] scratch*/; void* dqkv_split /*[N*L, 6d] 16-bit: [hi(3d) | lo(3d)]*/;
   int N, L, H; int causal;
   int lo8 = 0;           // out_split rows are [hi | lo8] (read for delta) and dqkv_split rows are written as [hi(3d) | lo8 (3d bytes) | unused]
+#ifdef MVLPT_ATTN_TRACE
+  long long* trace = nullptr;   // debug builds only (tools/attn_trace.py bwd): records of one workgroup of attn32r_bwd_kernel
+#endif
 };
 hipError_t launch_attn32_bwd(int dtype, const Attn32BwdArgs& a, hipStream_t s);
 

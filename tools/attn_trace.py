@@ -10,7 +10,45 @@ os.environ["MVLPT_ATTN_TRACE_FILE"] = "/tmp/attn_trace.bin"
 import numpy as np
 import torch
 from mvlpt_amd import engine as E, _lib
+BWD = len(sys.argv) > 1 and sys.argv[1] == "bwd"
+if BWD:
+    sys.argv.pop(1)
 N, L, H = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 205, 12)
+if BWD:
+    # the resident pair-attention BACKWARD (attn32r_bwd_kernel, cfg3's first kernel): workgroup (head 5, image N/2).  Points: 20 start,
+    # 21 K / V staging + own delta rows requested, 22 landed + barrier; phase A per own query tile: 23 own Q / dO pairs loaded, 24 S, dP,
+    # exp, dS of 13 key tiles done, 25 dQ accumulated, 26 dQ stored; 27 barrier behind phase A, 28 Q / dO staging requested, 29 landed +
+    # barrier; phase B per own key tile: 30 own K / V pairs loaded, 31 S, dP, P, dS of 13 query tiles, 32 dV accumulated, 33 dK
+    # accumulated, 34 stored; 35 end
+    d = H * 64
+    qkv = E.split_pair(torch.randn(N * L, 3 * d, device="cuda"), torch.float16)
+    out, lse = E.op_attention32_fwd_pair(qkv, N, L, H, False)
+    dout = E.split_pair(torch.randn(N * L, d, device="cuda"), torch.float16)
+    dqkv = torch.empty(N * L, 6 * d, device="cuda", dtype=torch.float16)
+    delta = torch.empty(N * H * L, device="cuda", dtype=torch.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        _lib.lib.mvlpt_op_attention32_bwd(1, qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), N, L, H, 0, st)
+    torch.cuda.synchronize()
+    raw = np.fromfile("/tmp/attn_trace.bin", dtype=np.int64).reshape(8, 256)
+    names = {(20, 21): "prologue: K / V staging requests, delta of the own rows", (21, 22): "wait for K, V + barrier",
+             (22, 23): "phase A: own Q / dO pairs from memory", (26, 23): "phase A: own Q / dO pairs from memory (2nd tile)",
+             (23, 24): "phase A: S, dP (78 MFMAs), exp, dS of 13 key tiles", (24, 25): "phase A: dQ = dS K (39 x 3 MFMAs)", (25, 26): "phase A: dQ stores",
+             (26, 27): "barrier behind phase A (waits for the slowest wave)", (22, 27): "no phase-A tile", (27, 28): "Q / dO staging requests", (28, 29): "wait for Q, dO + barrier",
+             (29, 30): "phase B: own K / V pairs from memory", (34, 30): "phase B: own K / V pairs from memory (2nd tile)",
+             (30, 31): "phase B: S, dP (78 MFMAs), exp, P, dS of 13 query tiles", (31, 32): "phase B: dV = P^T dO", (32, 33): "phase B: dK = dS^T Q",
+             (33, 34): "phase B: dK / dV stores", (34, 35): "end"}
+    for w in range(7):
+        r = raw[w][raw[w] != 0]
+        if len(r) == 0:
+            continue
+        p, t = (r >> 56) & 0xff, r & ((1 << 56) - 1)
+        tot = int(t[-1] - t[0])
+        print(f"wave {w}: {tot} ticks (s_memtime; ~ shader cycles on this box: 12 heads per CU x this = the launch)")
+        for k in range(1, len(p)):
+            key = (int(p[k - 1]), int(p[k]))
+            print(f"    {names.get(key, str(key)):62s} {int(t[k] - t[k - 1]):7d} ticks  ({100 * (t[k] - t[k - 1]) / tot:4.1f} %)")
+    sys.exit(0)
 d = H * 64
 qkv = E.split_pair(torch.randn(N * L, 3 * d, device="cuda"), torch.float16)
 out = torch.zeros(N * L, 2 * d, device="cuda", dtype=torch.float16)
