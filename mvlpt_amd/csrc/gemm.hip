@@ -373,6 +373,233 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 || BM_ * BN_ / NW > 8192) ? 1 : 2
   }
 }
 
+#ifdef MVLPT_BREG
+// ---------------------------------------------------------------------------------------------- experiment (debug builds only)
+// "weight fragments straight from L2 into registers, the whole LDS ring for A".  256x256 tile, 8 waves of 128x64
+// as above, but only the A operand travels through LDS (ring of MVLPT_BREG_NS stages of 32 KiB, NS-1 stages ahead); every wave reads
+// the B fragments of ITS 64 columns with global_load_dwordx4 into registers, one K-stage ahead (two buffers of 32 VGPRs, the
+// K loop unrolled by two so that both are statically indexed).  vmcnt retires in order: the wait for B(f+1) at the end of stage f
+// may leave only the A pieces issued behind it in flight.  Dedicated epilogue scratch (a 32-KiB slot does not hold the 36 KiB).
+// tools/build_variant.sh breg -DMVLPT_BREG; MVLPT_GEMM_BREG=1 selects it for the single-operand 256x256 launches.
+#ifndef MVLPT_BREG_NS
+#define MVLPT_BREG_NS 3
+#endif
+#include <type_traits>
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_breg_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using v8 = typename Vec<T>::v8;
+  constexpr int BM_ = 256, BN = 256, NW = 8, NS = MVLPT_BREG_NS, WCN = 4, WMF = 8;
+  constexpr int STAGE = BM_ * BK * 2, A_IT = BM_ / 8 / NW;
+  constexpr bool CAN_FOLD = epi_folds(EPI);
+  char* const scr = smem + NS * STAGE;
+  [[maybe_unused]] char* const xlds = scr + NW * EPI_SCRATCH_PER_WAVE;
+  [[maybe_unused]] char* const xtab = xlds + xlds_tab(g.fold_ntp);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = g.M, N = g.N, K = g.K;
+  const int lda = g.lda ? g.lda : K, ldb = g.ldb ? g.ldb : K;
+  const T* __restrict__ A = (const T*)g.A;
+  const T* __restrict__ Bt = (const T*)g.Bt;
+  const int G = gridDim.x, b = blockIdx.x;
+  const int tilesN = N / BN;
+  const int ntiles = ((M + BM_ - 1) / BM_) * tilesN;
+  const int gq = G >> 3, gr = G & 7, xcd = b & 7;
+  const int b_remap = (xcd < gr ? xcd * (gq + 1) : gr * (gq + 1) + (xcd - gr) * gq) + (b >> 3);
+  auto tile_mn = [&](int t, int& tm, int& tn) { tm = t / tilesN; tn = t - tm * tilesN; };
+  auto tile_of = [&](int round) -> int {
+    const int base = round * G;
+    return base + ((base + G <= ntiles) ? b_remap : b);
+  };
+  const int srow = lane >> 3, scol = ((lane & 7) ^ srow) * 8;
+  // (M % 256 == 0 in this experiment: no edge rows to clamp -> a wave-uniform base per tile + ONE 32-bit lane offset)
+  const char* ap_base;
+  const unsigned ap_voff = (unsigned)(srow * lda + scol) * 2u;
+  auto set_ptrs = [&](int t) {
+    int tm, tn;
+    tile_mn(t, tm, tn);
+    ap_base = (const char*)(A + (size_t)(tm * BM_ + wave * 8) * lda);
+  };
+  const int nk = K / BK;
+  int lround = 0, lt = tile_of(0), lkt = 0, lslot = 0;
+  if (lt >= ntiles) return;
+  set_ptrs(lt);
+  auto issue = [&]() -> bool {
+    if (lt >= ntiles) return false;
+    char* base = smem + lslot * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) glds16(ap_base + ((size_t)i * NW * 8 * lda + lkt * BK) * 2 + ap_voff, base + (i * NW + wave) * 1024);
+    if constexpr (CAN_FOLD) {
+      if (lkt == nk - 1) {
+        const int cpr = g.fold_ntp >> 1;
+        int ltm, ltn;
+        tile_mn(lt, ltm, ltn);
+        const long first = (long)ltm * BM_ * cpr, last = (long)M * cpr - 1;
+        for (int q0 = wave * 64; q0 < BM_ * cpr; q0 += NW * 64) {
+          long q = first + q0 + lane; q = q < last ? q : last;
+          glds16(g.fold_part + q * 4, xlds + q0 * 16);
+        }
+        const int n0 = ltn * BN + (lane < BN / 4 ? lane : BN / 4 - 1) * 4;
+        if (wave == NW - 1) glds16(g.fold_colsum + n0, xtab + XLDS_COLSUM);
+        if (wave == NW - 2) glds16(g.bias + n0, xtab + XLDS_BIAS);
+      }
+    }
+    lslot = lslot + 1 == NS ? 0 : lslot + 1;
+    if (++lkt == nk) {
+      lkt = 0;
+      lt = tile_of(++lround);
+      if (lt < ntiles) set_ptrs(lt);
+    }
+    return true;
+  };
+  const int wm = wave / WCN, wn = wave % WCN;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int a_off = (wm * (WMF * 16) + fr) * 128;
+  const int c0 = ((0 + fg) ^ (fr & 7)) * 16, c1 = ((4 + fg) ^ (fr & 7)) * 16;
+  // the lane's B rows: fragment j = weight row n0 + wn*64 + j*16 + fr, k-step ks = elements ks*32 + fg*8 .. +7 of the stage
+  // (wave-uniform base in SGPRs + ONE 32-bit lane offset: the saddr form of global_load)
+  const char* bq_base;
+  const unsigned bq_voff = (unsigned)(fr * ldb + fg * 8) * 2u;
+  auto set_bptr = [&](int t) {
+    int tm, tn;
+    tile_mn(t, tm, tn);
+    bq_base = (const char*)(Bt + (size_t)(tn * BN + wn * 64) * ldb);
+  };
+  v8 bq[2][2][4];
+  auto load_bq = [&](v8 (&q)[2][4], int kt) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // from inline asm (hipcc's own loads take a 64-bit VGPR address per fragment and spill the fragments): the compiler does not
+        // know the result is pending — every use sits behind the explicit vmcnt wait + barrier that ends the stage
+        const char* bj = bq_base + ((size_t)j * 16 * ldb + kt * BK) * 2;
+        if (ks == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q[ks][j]) : "v"(bq_voff), "s"(bj) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(q[ks][j]) : "v"(bq_voff), "s"(bj) : "memory");
+      }
+  };
+  int t = tile_of(0);
+  set_bptr(t);
+  load_bq(bq[0], 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i) issue();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * A_IT) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int slot = 0;
+  for (int round = 0; t < ntiles; t = tile_of(++round)) {
+    f32x4 acc[WMF / 4][4][4];
+#pragma unroll
+    for (int i = 0; i < WMF; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i >> 2][i & 3][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool dma_first = wave < NW / 2;
+    const char* bq_next;
+    {
+      const int nt = tile_of(round + 1);
+      int tm, tn;
+      tile_mn(nt < ntiles ? nt : t, tm, tn);
+      bq_next = (const char*)(Bt + (size_t)(tn * BN + wn * 64) * ldb);
+    }
+    auto stage = [&](auto curc, int kt) {
+      constexpr int CUR = decltype(curc)::value;
+      // B of the next stage first (so that the A pieces issued behind it may stay in flight across the wait below)
+      // (branch-free: behind the tile's last stage comes stage 0 of the next tile — of this one again when there is none)
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const bool last = kt + 1 >= nk;
+        bq_base = last ? bq_next : bq_base;
+        load_bq(bq[CUR ^ 1], last ? 0 : kt + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bool issued = false;
+      if (dma_first) issued = issue();
+      const char* base = smem + slot * STAGE;
+      constexpr int PAIRS = WMF / 2, GROUPS = 2 * PAIRS;
+      v8 afr[2][2];
+      auto load_a2 = [&](int ks, int pair, v8 (&af)[2]) {
+        const int c = ks ? c1 : c0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *(const v8*)(base + a_off + (pair * 2 + i) * 2048 + c);
+      };
+      load_a2(0, 0, afr[0]);
+#pragma unroll
+      for (int sg = 0; sg < GROUPS; ++sg) {
+        const int ks = sg / PAIRS, pair = sg % PAIRS, cur = sg & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const int ai = pair * 2;
+          acc[ai >> 2][ai & 3][0] = mfma16<T>(bq[CUR][ks][0], afr[cur][0], acc[ai >> 2][ai & 3][0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (sg + 1 < GROUPS) load_a2((sg + 1) / PAIRS, (sg + 1) % PAIRS, afr[(sg + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (i == 0 && j == 0) continue;
+            const int ai = pair * 2 + i;
+            acc[ai >> 2][ai & 3][j] = mfma16<T>(bq[CUR][ks][j], afr[cur][i], acc[ai >> 2][ai & 3][j]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!dma_first) issued = issue();
+      // A(f+1) (issued NS-2 stages ago) and B(f+1) (this stage) must have landed; only the A pieces issued behind B may stay
+      if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      slot = slot + 1 == NS ? 0 : slot + 1;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      stage(std::integral_constant<int, 0>{}, kt);
+      stage(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    int tm, tn;
+    tile_mn(t, tm, tn);
+    if constexpr (CAN_FOLD) {
+      if (tid < BM_) fold_build_coef(g, xlds, xtab, tid);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int hh = 0; hh < WMF / 4; ++hh)
+      epilogue_store<T, EPI>(g, acc[hh], tm * BM_ + wm * (WMF * 16) + hh * 64, tn * BN + wn * 64, lane,
+                             LinearRows<144>{scr + wave * EPI_SCRATCH_PER_WAVE}, LinearRows<272>{scr + wave * EPI_SCRATCH_PER_WAVE},
+                             FoldCtx{xlds, xtab, wm * (WMF * 16) + hh * 64, wn, WCN, g.ln_split ? 1 : 0});
+    __builtin_amdgcn_s_barrier();
+    if constexpr (epi_ln_producer(EPI)) {
+      if (tid < BM_) {
+        const int row = tm * BM_ + tid;
+        if (row < M) {
+          const float2* p = (const float2*)(xlds + (size_t)tid * WCN * 8);
+#pragma unroll
+          for (int k = 0; k < WCN / 2; ++k)
+            *(float2*)(g.ln_part + ((size_t)row * g.ln_ntp + tn * (WCN / 2) + k) * 2) = float2{p[2 * k].x + p[2 * k + 1].x, p[2 * k].y + p[2 * k + 1].y};
+        }
+      }
+    }
+  }
+}
+template <typename T, int EPI>
+static hipError_t launch_breg(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+  constexpr int LDS = MVLPT_BREG_NS * 256 * BK * 2 + 8 * EPI_SCRATCH_PER_WAVE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_breg_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int lds = LDS + (epi_folds(EPI) ? xlds_bytes(g.fold_ntp) : (epi_ln_producer(EPI) ? XLDS_BYTES : 0));
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const int cus = stream_cus(s);
+  const int tiles = ((g.M + 255) / 256) * (g.N / 256);
+  hipExtLaunchKernelGGL((gemm_breg_kernel<T, EPI>), dim3(tiles < cus ? tiles : cus), dim3(512), lds, s, ea, eb, 0, g);
+  return hipGetLastError();
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------- phased variant
 // 256x128 tile, 8 waves, 3-deep ring, same data movement as above, but every K-stage is cut into FOUR barrier-
 // separated phases  R0 | M0 | R1 | M1  (R = LDS-DMA issue + ds_read of one 32-deep k-step, M = its 16 MFMAs) and waves
@@ -1070,6 +1297,10 @@ static hipError_t launch_one(const GemmArgs& g, hipStream_t s, hipEvent_t ea, hi
   }
   if (geo >= 2 && big) {
     *tile_m = 256; *tile_n = 256;
+#ifdef MVLPT_BREG
+    static const int breg = getenv("MVLPT_GEMM_BREG") ? atoi(getenv("MVLPT_GEMM_BREG")) : 0;
+    if (breg && g.a_split == 0 && g.M % 256 == 0 && g.K % 128 == 0 && g.K / BK >= MVLPT_BREG_NS) return ea == (hipEvent_t)-1 ? hipSuccess : launch_breg<T, EPI>(g, s, ea, eb);
+#endif
     return ea == (hipEvent_t)-1 ? hipSuccess : launch_geo<T, EPI, 256, 256, 8, 2>(g, 1, s, ea, eb);
   }
   // (a folded consumer with 8-slot rows needs 20 KiB behind its ring: the 3-deep 256x128 ring has 16 left -> 256x256 or 128x128)
