@@ -85,6 +85,33 @@ __device__ __forceinline__ f32x4 load_pair4(const T* p, size_t lo_off) {
   for (int e = 0; e < 4; ++e) r[e] = to_f32<T>(hi[e]) + to_f32<T>(lo[e]);      // exact: <= 22 significant bits
   return r;
 }
+// This lane's part of delta = rowsum(dO * O) of one (row, head): dO as the own-row fragments (gh, gl: elements 32 ks + 8 fg + e, the
+// registers phase A multiplies with), O read in the same layout (16-bit plane + 16-bit or e5m2 residual plane) — half the load
+// instructions of a 4-column walk, and no second read of dO.  quad_sum() of the result is the row's delta.
+template <typename T>
+__device__ __forceinline__ float delta_part(const T* orow_head, size_t d, int col_head, int fg, int lo8,
+                                            const typename Vec<T>::v8 (&gh)[2], const typename Vec<T>::v8 (&gl)[2]) {
+  using v8 = typename Vec<T>::v8;
+  float acc = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int c = ks * 32 + fg * 8;
+    const v8 oh = *(const v8*)(orow_head + c);
+    float o[8];
+    if (!lo8) {
+      const v8 ol = *(const v8*)(orow_head + d + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = to_f32<T>(oh[e]) + to_f32<T>(ol[e]);
+    } else {
+      const uint2 w = *(const uint2*)((const char*)(orow_head - col_head) + 2 * d + col_head + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = join_lo8<T>(oh[e], w.x, e); o[e + 4] = join_lo8<T>(oh[e + 4], w.y, e); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += o[e] * (to_f32<T>(gh[ks][e]) + to_f32<T>(gl[ks][e]));
+  }
+  return acc;
+}
 
 // head-chunk workgroup order: consecutive block ids go round-robin over the 8 XCDs, so the chunks of one head take ids
 // that are 8 apart (same XCD, same L2)
@@ -645,6 +672,10 @@ __global__ __launch_bounds__(SNT * 64, 4) void attn32t_bwd_kernel(Attn32BwdArgs 
   const size_t ld = 6 * (size_t)d, lo = 3 * (size_t)d, gld = 2 * (size_t)d;
   const T* base = (const T*)a.qkv_split + (size_t)n * L * ld + h * 64;
   const T* gbase = (const T*)a.dout_split + (size_t)n * L * gld + h * 64;
+#ifdef MVLPT_ATTN_TRACE
+  int atr_n = 0;
+#endif
+  MVLPT_ATRB(40);
   stage_short<T>(I0h, I0l, base + d, lo, ld, L, wave, lane);          // K
   stage_short<T>(I1h, I1l, base + 2 * d, lo, ld, L, wave, lane);      // V
   const size_t stat0 = ((size_t)n * a.H + h) * L;
@@ -653,24 +684,27 @@ __global__ __launch_bounds__(SNT * 64, 4) void attn32t_bwd_kernel(Attn32BwdArgs 
   v8 Qh[2], Ql[2], Gh[2], Gl[2], Kh[2], Kl[2], Vh[2], Vl[2];
   load_own_pair<T>(Qh, Ql, base + (size_t)rc * ld, lo, fg);
   load_own_pair<T>(Gh, Gl, gbase + (size_t)rc * gld, d, fg);
-  load_own_pair<T>(Kh, Kl, base + d + (size_t)rc * ld, lo, fg);
-  load_own_pair<T>(Vh, Vl, base + 2 * d + (size_t)rc * ld, lo, fg);
   float dl = 0.f;       // delta = rowsum(dO * O) of the own query row
   {
+    // dO of the own row is in registers already (Gh, Gl): O in the same fragment layout, no second read of dO
     const T* orow = (const T*)a.out_split + ((size_t)n * L + rc) * gld + h * 64;
-    const T* grow = gbase + (size_t)rc * gld;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 o = load_pair4_m<T>(orow + 16 * t + 4 * fg, d, h * 64 + 16 * t + 4 * fg, a.lo8), g = load_pair4<T>(grow + 16 * t + 4 * fg, d);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dl += o[e] * g[e];
-    }
+    dl = delta_part<T>(orow, d, h * 64, fg, a.lo8, Gh, Gl);
     dl = quad_sum(dl);
   }
   const float nlse = -a.lse[stat0 + rc] * LOG2E;
   if (fg == 0) { nlse_s[row] = nlse; del_s[row] = dl; }
+  MVLPT_ATRB(41);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  MVLPT_ATRB(42);
+  // the own key / value rows (phase B) out of the K / V images that have just landed — not a second time from memory (rows >= L of
+  // an image hold row L-1, like the clamped global row); read before phase A, the images are restaged behind it
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    Kh[ks] = frag_rows<T>(I0h, wave, ks, fr, fg); Kl[ks] = frag_rows<T>(I0l, wave, ks, fr, fg);
+    Vh[ks] = frag_rows<T>(I1h, wave, ks, fr, fg); Vl[ks] = frag_rows<T>(I1l, wave, ks, fr, fg);
+  }
+  asm volatile("" ::: "memory");
   const bool active = wave < nt;
   T* orow = (T*)a.dqkv_split + ((size_t)n * L + rc) * ld + h * 64;
   // ---- phase A: own query tile -> dQ
@@ -693,19 +727,25 @@ __global__ __launch_bounds__(SNT * 64, 4) void attn32t_bwd_kernel(Attn32BwdArgs 
       }
     }
     f32x4 dQ[4];
+    MVLPT_ATRB(43);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dQ[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     accum_all3<T>(dQ, I0h, I0l, dS, 0, kt_end, fr, fg);
+    MVLPT_ATRB(44);
     if (row < L) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) store_pair4_m<T>(orow + 16 * dt + 4 * fg, lo, h * 64 + 16 * dt + 4 * fg, dQ[dt] * SCALE, a.lo8);
     }
   }
+  MVLPT_ATRB(45);
   __syncthreads();
+  MVLPT_ATRB(46);
   stage_short<T>(I0h, I0l, base, lo, ld, L, wave, lane);              // Q
   stage_short<T>(I1h, I1l, gbase, d, gld, L, wave, lane);             // dO
+  MVLPT_ATRB(47);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  MVLPT_ATRB(48);
   // ---- phase B: own key tile -> dK, dV
   if (active) {
     const int qt_lo = CAUSAL ? wave : 0;
@@ -728,10 +768,12 @@ __global__ __launch_bounds__(SNT * 64, 4) void attn32t_bwd_kernel(Attn32BwdArgs 
       }
     }
     f32x4 dK[4], dV[4];
+    MVLPT_ATRB(49);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dK[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     accum_all3<T>(dV, I1h, I1l, P, qt_lo, nt, fr, fg);
     accum_all3<T>(dK, I0h, I0l, dS, qt_lo, nt, fr, fg);
+    MVLPT_ATRB(50);
     if (row < L) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -740,6 +782,7 @@ __global__ __launch_bounds__(SNT * 64, 4) void attn32t_bwd_kernel(Attn32BwdArgs 
       }
     }
   }
+  MVLPT_ATRB(51);
 }
 
 // ------------------------------------------------------------------------------------------------ resident, medium sequences
@@ -877,15 +920,9 @@ __global__ __launch_bounds__(RNW * 64) void attn32r_bwd_kernel(Attn32BwdArgs a) 
   for (int o = 0; o < 2; ++o) {
     const int row = (wave + o * RNW) * 16 + fr, rc = row < L ? row : L - 1;
     const T* orow = (const T*)a.out_split + ((size_t)n * L + rc) * gld + h * 64;
-    const T* grow = gbase + (size_t)rc * gld;
-    float acc = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const f32x4 ov = load_pair4_m<T>(orow + 16 * t + 4 * fg, d, h * 64 + 16 * t + 4 * fg, a.lo8), g = load_pair4<T>(grow + 16 * t + 4 * fg, d);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc += ov[e] * g[e];
-    }
-    dl[o] = quad_sum(acc);
+    v8 gh[2], gl[2];
+    load_own_pair<T>(gh, gl, gbase + (size_t)rc * gld, d, fg);
+    dl[o] = quad_sum(delta_part<T>(orow, d, h * 64, fg, a.lo8, gh, gl));
     nlse[o] = -a.lse[stat0 + rc] * LOG2E;
     if (fg == 0 && row < RROWS) { nlse_s[row] = nlse[o]; del_s[row] = dl[o]; }
   }

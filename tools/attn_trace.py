@@ -13,7 +13,7 @@ from mvlpt_amd import engine as E, _lib
 BWD = len(sys.argv) > 1 and sys.argv[1] == "bwd"
 if BWD:
     sys.argv.pop(1)
-N, L, H = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 205, 12)
+N, L, H = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 and sys.argv[1] != "short" else (256, 205, 12)
 if BWD:
     # the resident pair-attention BACKWARD (attn32r_bwd_kernel, cfg3's first kernel): workgroup (head 5, image N/2).  Points: 20 start,
     # 21 K / V staging + own delta rows requested, 22 landed + barrier; phase A per own query tile: 23 own Q / dO pairs loaded, 24 S, dP,
@@ -48,6 +48,34 @@ if BWD:
         for k in range(1, len(p)):
             key = (int(p[k - 1]), int(p[k]))
             print(f"    {names.get(key, str(key)):62s} {int(t[k] - t[k - 1]):7d} ticks  ({100 * (t[k] - t[k - 1]) / tot:4.1f} %)")
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "short":
+    # the text tower's causal backward (attn32t_bwd_kernel, L <= 80): workgroup (head 5, sequence N/2).  Points: 40 start, 41 K / V staging +
+    # own rows + delta requested, 42 landed + barrier, 43 phase A: S, dP, exp, dS of the own query tile, 44 dQ accumulated, 45 dQ stores
+    # issued, 46 barrier behind phase A, 47 Q / dO staging requested, 48 landed + barrier, 49 phase B: S, dP, P, dS, 50 dV / dK accumulated, 51 end
+    N, L, H = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (100, 77, 8)
+    d = H * 64
+    qkv = E.split_pair(torch.randn(N * L, 3 * d, device="cuda"), torch.float16)
+    out, lse = E.op_attention32_fwd_pair(qkv, N, L, H, True)
+    dout = E.split_pair(torch.randn(N * L, d, device="cuda"), torch.float16)
+    dqkv = torch.empty(N * L, 6 * d, device="cuda", dtype=torch.float16)
+    delta = torch.empty(N * H * L, device="cuda", dtype=torch.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        _lib.lib.mvlpt_op_attention32_bwd(1, qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), N, L, H, 1, st)
+    torch.cuda.synchronize()
+    raw = np.fromfile("/tmp/attn_trace.bin", dtype=np.int64).reshape(8, 256)
+    names = {(40, 41): "requests: K / V staging, own rows, delta", (41, 42): "wait + barrier", (42, 43): "phase A: S, dP, exp, dS (own query tile)",
+             (43, 44): "phase A: dQ accumulation", (44, 45): "phase A: dQ stores issued", (45, 46): "barrier behind phase A", (42, 45): "no phase-A tile",
+             (46, 47): "Q / dO staging requests", (47, 48): "wait + barrier", (48, 49): "phase B: S, dP, P, dS (own key tile)", (49, 50): "phase B: dV, dK accumulation",
+             (50, 51): "phase B: stores issued", (48, 51): "no phase-B tile"}
+    t0 = min(int(raw[w][raw[w] != 0][0] & ((1 << 56) - 1)) for w in range(5))
+    for w in range(5):
+        r = raw[w][raw[w] != 0]
+        p, t = (r >> 56) & 0xff, r & ((1 << 56) - 1)
+        print(f"wave {w}: {int(t[-1] - t[0])} ticks from its start to its end (s_memtime, 100 MHz x 21 ~ shader cycles?)  start +{int(t[0]) - t0}")
+        for k in range(1, len(p)):
+            print(f"    {names.get((int(p[k - 1]), int(p[k])), str((int(p[k - 1]), int(p[k])))):50s} {int(t[k] - t[k - 1]):7d} ticks")
     sys.exit(0)
 d = H * 64
 qkv = E.split_pair(torch.randn(N * L, 3 * d, device="cuda"), torch.float16)
