@@ -13,6 +13,7 @@ dout = E.split_pair(torch.randn(N * L, d, device="cuda"), torch.float16)
 dq = E.op_attention32_bwd_mixed(qkv, out, dout, lse, N, L, H, bool(CAUSAL))
 torch.cuda.synchronize()
 fp = hashlib.sha256(dq.cpu().numpy().tobytes()).hexdigest()[:16]
+fpo = hashlib.sha256(out.cpu().numpy().tobytes() + lse.cpu().numpy().tobytes()).hexdigest()[:16]
 dqkv = torch.zeros_like(dq); delta = torch.empty(N * H * L, device="cuda")
 from mvlpt_amd import _lib
 P = lambda t: t.data_ptr()
@@ -27,4 +28,15 @@ for _ in range(7):
     for _ in range(100 if L < 100 else 10): run()
     e.record(); torch.cuda.synchronize()
     ts.append(s.elapsed_time(e) * (10 if L < 100 else 100))
+o2 = torch.zeros_like(out); l2 = torch.zeros_like(lse)
+runf = lambda: _lib.lib.mvlpt_op_attention32_fwd_mixed(1, P(qkv), P(o2), P(l2), N, L, H, CAUSAL, 0, st)
+for _ in range(10): runf()
+torch.cuda.synchronize()
+tf = []
+for _ in range(7):
+    s.record()
+    for _ in range(100 if L < 100 else 10): runf()
+    e.record(); torch.cuda.synchronize()
+    tf.append(s.elapsed_time(e) * (10 if L < 100 else 100))
+print(f"   forward: out+lse sha256 {fpo}  {min(tf):.1f} us best, {sorted(tf)[3]:.1f} median   (MVLPT_ATTN32T_PERSIST={os.environ.get('MVLPT_ATTN32T_PERSIST', '1')})")
 print(f"{os.path.basename(os.environ.get('MVLPT_HIP_LIB', 'libmvlpt_hip.so'))}: dqkv sha256 {fp}  backward {min(ts):.1f} us best, {sorted(ts)[3]:.1f} median (N = {N}, L = {L}, H = {H}, causal = {CAUSAL})")
