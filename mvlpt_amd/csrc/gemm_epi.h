@@ -13,6 +13,9 @@ constexpr int BK = 64;
 // scratch (the ring slot that has just been released) and writes / reads global memory in full 128-256-byte
 // row segments (16 B per lane).  fp16 outputs are staged as 16-bit, 32 rows per pass; everything that is
 // combined with another global operand in fp32 (residual, GELU' * u) is staged as fp32, 16 rows per pass.
+#ifndef MVLPT_RESIDP_WIDE
+#define MVLPT_RESIDP_WIDE 1      // 0: the four-columns-per-lane walk of round 5 (A/B builds)
+#endif
 constexpr int EPI_SCRATCH_PER_WAVE = 4608;   // 32 rows x (128 + 16) B  >=  16 rows x (256 + 16) B
 
 // wave-private scratch rows: either one contiguous region, or (phased kernel) the wave's OWN six 1-KiB LDS-DMA slabs
@@ -115,6 +118,13 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+// ... over the 8 lanes of a half row (lanes 8k .. 8k+7)
+__device__ __forceinline__ float row8_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
   return v;
 }
 // 16-bit copy of four values in the A-operand formats of kernels.h (0 single, 1 hi|lo pair, 2 mixed pair); `base` [M, N or 2N]
@@ -230,6 +240,59 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, const f32x4 (&
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // scratch is rewritten by the next pass
       }
+    }
+  } else if constexpr (EPI == EPI_RESIDP_LN && MVLPT_RESIDP_WIDE && sizeof(T) == 2 && !__is_same(T, bf16)) {
+    // Packed residual stream, EIGHT columns per lane behind the transpose (8 lanes = the 64 columns of a row, 8 rows per pass): the
+    // 16-bit plane moves 16 B per lane and the byte plane 8 B — half the load / store instructions of the four-column walk below
+    // (32 instead of 64 per 64x64 block; 1 KiB and 512 B per instruction instead of 512 and 256).  Under a saturated memory system an
+    // epilogue is paced by its number of requests as much as by its bytes (NOTES round 6).
+    int c = lane & 7, rq = lane >> 3;
+    asm volatile("" : "+v"(c), "+v"(rq));      // (opaque to loop-invariant code motion, see below)
+    v8 uv[4][2];
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 lw[4][2];
+#pragma unroll
+    for (int i = 2 * H0; i < 2 * H1; ++i)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        int m = mbase + i * 16 + it * 8 + rq;
+        m = m < M ? m : M - 1;
+        const size_t o = (size_t)m * N + nbase + c * 8;
+        uv[i][it] = __builtin_nontemporal_load((const v8*)((const T*)g.rp_hi_in + o));
+        lw[i][it] = __builtin_nontemporal_load((const u32x2*)(g.rp_lo_in + o));
+      }
+    f32x4 cb0 = {0.f, 0.f, 0.f, 0.f}, cb1 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) { cb0 = *(const f32x4*)(g.bias + nbase + c * 8); cb1 = *(const f32x4*)(g.bias + nbase + c * 8 + 4); }
+#pragma unroll
+    for (int i = 2 * H0; i < 2 * H1; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(rows32(fr) + (j * 16 + fg * 4) * 4) = acc[i][j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int r = it * 8 + rq;
+        f32x4 v0 = *(const f32x4*)(rows32(r) + c * 32), v1 = *(const f32x4*)(rows32(r) + c * 32 + 16);
+        const int m = mbase + i * 16 + r;
+        const size_t o = (size_t)m * N + nbase + c * 8;
+        const v8 u = uv[i][it];
+        v0 += respk_join4(f16x4{u[0], u[1], u[2], u[3]}, lw[i][it][0]) + cb0;
+        v1 += respk_join4(f16x4{u[4], u[5], u[6], u[7]}, lw[i][it][1]) + cb1;
+        // partial sums of the row over this wave's 64 columns: the 8 lanes of the row hold them
+        float s1 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+        float s2 = ((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) + ((v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]));
+        s1 = row8_sum(s1); s2 = row8_sum(s2);
+        if (c == 0) *(float2*)(fc.xl + ((size_t)(fc.mrel + i * 16 + r) * fc.wcn + fc.wn) * 8) = float2{s1, s2};
+        f16x4 h0, h1;
+        u32x2 lo;
+        lo[0] = respk_split4(v0, h0);
+        lo[1] = respk_split4(v1, h1);
+        if (m < M) {
+          __builtin_nontemporal_store(v8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]}, (v8*)((T*)g.out + o));
+          __builtin_nontemporal_store(lo, (u32x2*)(g.rp_lo_out + o));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   } else {
     int c = lane & 15, rq = lane >> 4;                        // 16 lanes x 16 B = one 256-B row segment (fp32)
